@@ -1,0 +1,144 @@
+/* solorl.h -- C ABI of the MI355X-native Solo8/Solo12 rollout engine.
+ *
+ * Drop-in boundary for the reference's vec-env layer.  Each entry point
+ * replaces what the reference does through N worker processes and pickled Pipe messages:
+ *
+ *   solorl_create          <- agents/ppo/envs.py:14-30 (make_vec_envs), :66-89 (VecEnvWrapper.__init__
+ *                             forking N `simple_worker`s, each building SoloBaseEnv(config):
+ *                             baseEnv.py:7-40 -> solo.py:55-67)
+ *   solorl_reset           <- agents/ppo/envs.py:97-100,198-200 -> baseEnv.py:70-82 (reset)
+ *   solorl_step            <- agents/ppo/envs.py:91-95,189-196 -> :36-40 (worker: step + auto-reset)
+ *                             -> baseEnv.py:42-68 (step)
+ *   solorl_get_observation <- agents/ppo/envs.py:102-105,206-208 -> baseEnv.py:88-89
+ *   solorl_dims            <- agents/ppo/envs.py:112-114 (get_spaces) -> baseEnv.py:20-28
+ *   solorl_increment_curriculum <- agents/ppo/envs.py:125-127 (pointgoal: solo.py:332-334)
+ *   solorl_get_state / solorl_set_state : no reference counterpart (parity-test hooks)
+ *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
+ *
+ * Plain pointers and sizes only; no torch types.  All array arguments are DEVICE pointers
+ * (HIP, the device the handle was created on); the engine never retains them past the stream
+ * work of the call.  All work is enqueued on the `stream` argument (a hipStream_t passed as
+ * void*; NULL = the null stream) and no entry point synchronises the host except
+ * solorl_create/solorl_destroy/solorl_get_state/solorl_set_state.
+ *
+ * Error convention: every function returns 0 on success or a negative code; the message is
+ * available from solorl_last_error() (thread-local).  A per-env numeric failure (NaN/Inf state)
+ * is NOT an error: the env is force-terminated, reset and counted in info.nan_reset.
+ *
+ * A handle is not thread-safe; one caller thread and one GPU per handle.
+ */
+#ifndef SOLORL_H
+#define SOLORL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SOLORL_ROBOT_SOLO8 = 0, SOLORL_ROBOT_SOLO12 = 1 };
+enum { SOLORL_TASK_STAND = 0, SOLORL_TASK_WALK = 1, SOLORL_TASK_POINTGOAL = 2 };
+enum { SOLORL_CONTROL_TORQUE = 0, SOLORL_CONTROL_PD = 1 };
+enum { SOLORL_PRECISION_F32 = 0, SOLORL_PRECISION_F64 = 1 };
+
+enum {
+  SOLORL_OK = 0,
+  SOLORL_ERR_INVALID = -1,   /* bad argument / config */
+  SOLORL_ERR_NODEVICE = -2,  /* no usable HIP device */
+  SOLORL_ERR_HIP = -3,       /* a HIP runtime call failed */
+  SOLORL_ERR_STATE = -4      /* step() before reset() (reference baseEnv.py:43 assert) */
+};
+
+/* Task/robot/physics configuration: the YAML keys the reference reads in baseEnv.py:8-16,164
+ * plus the Bullet parameters the reference leaves at PyBullet defaults. */
+typedef struct solorl_config {
+  int32_t robot;            /* SOLORL_ROBOT_*  (from model_urdf basename / `solo12: True`) */
+  int32_t task;             /* SOLORL_TASK_*   (config 'task', baseEnv.py:11) */
+  int32_t control;          /* SOLORL_CONTROL_* (config 'control', baseEnv.py:10; pd = pd/fpd/fixed_pd) */
+  int32_t frame_skip;       /* config 'frame_skip' (default 4) */
+  int32_t episode_length;   /* config 'episode_length' (baseEnv.py:164) */
+  int32_t num_history_stack;/* config 'num_history_stack' (0..2 supported) */
+  int32_t hold_torque;      /* 0: torque acts on sub-step 1 only (Bullet clears it, K8); 1: held */
+  int32_t use_urdf_inertia; /* 0: Bullet default box inertia from collision AABB (K2); 1: URDF tensor */
+  int32_t solver_iterations;/* PGS iterations (PyBullet default 50, K7) */
+  int32_t settle_min;       /* reset: K ~ U{settle_min .. settle_max} zero-torque control steps */
+  int32_t settle_max;       /*        (baseEnv.py:79: randint(5,12) -> 5..11)                      */
+  int32_t disable_termination; /* parity runs: never set done */
+  int32_t precision;        /* SOLORL_PRECISION_*: arithmetic type of the HIP engine */
+  int32_t reserved0;
+  double kp, kd;            /* config 'gains' (configs/basic_pd.yaml:6) */
+  double max_torque;        /* solo.py:53 max_joint_torque = 3 */
+  double sim_dt;            /* solo.py:22 scene_timestep = 1/240 */
+  double reward_dt;         /* stands in for the undefined scene.dt of baseEnv.py:137 (1/60) */
+  double gravity;           /* simulation.py:19: 9.81 (pointing -z) */
+  double erp;               /* contact/limit error-reduction (0.2, K7) */
+  double linear_slop;       /* PyBullet solver linearSlop 1e-5 */
+  double warmstart;         /* warm-start factor on cached normal impulses (0.85) */
+  double damping;           /* btMultiBody linear = angular damping 0.04 (K3) */
+  double max_velocity;      /* generalized velocity clamp 100 (K5) */
+  double joint_limit;       /* +-10 rad (URDF; solo.py:109) */
+  double goal_radius;       /* solo.py:141 goal_radius = 2.0 */
+} solorl_config;
+
+/* Struct-of-arrays info block (replaces the per-env dicts of baseEnv.py:62-66).  Every pointer is
+ * a device array of num_envs elements, or NULL to skip that field. */
+typedef struct solorl_info_soa {
+  uint8_t* timeout;          /* info['timeout'] (valid where done) */
+  uint8_t* success;          /* info['success'] (valid where done) */
+  uint8_t* nan_reset;        /* env was force-reset because its state went non-finite */
+  int32_t* episode_length;   /* info['episode_length'] = timestep */
+  float*   episode_reward;   /* info['episode_reward'] = LAST step reward (baseEnv.py:65) */
+  float*   goals_reached;    /* info['goals_reached'] */
+  float*   dr_stand;         /* info['dr/stand_rew'] running sum */
+  float*   dr_joint_pose;    /* info['dr/joint_pose_rew'] */
+  float*   dr_torque;        /* info['dr/torque_rew'] */
+  float*   dr_balance;       /* info['dr/roll_pitch_balance_rew'] */
+  float*   dr_progress;      /* info['dr/progress_rew'] */
+} solorl_info_soa;
+
+/* Physical + bookkeeping state of ONE env in a fixed, precision-independent (double) layout;
+ * used by solorl_get_state/solorl_set_state (HOST pointers) for parity tests. */
+#define SOLORL_STATE_MAX_DOF 12
+#define SOLORL_STATE_MAX_PRIMS 20
+#define SOLORL_STATE_MAX_OBS 42
+typedef struct solorl_env_state {
+  double pos[3], quat[4] /* x y z w */, lin_vel[3], ang_vel[3];
+  double q[SOLORL_STATE_MAX_DOF], qd[SOLORL_STATE_MAX_DOF], tau[SOLORL_STATE_MAX_DOF];
+  double lambda_prev[SOLORL_STATE_MAX_PRIMS];  /* warm-start normal impulses per collision primitive */
+  double hist[2][SOLORL_STATE_MAX_OBS];        /* state_history, [0] = newest */
+  double goal[2], potential, progress, goals_reached, env_goals_reached;
+  double dr[5];                                /* stand, joint_pose, torque, balance, progress */
+  int32_t timestep, need_reset, contact_mask /* bit p: primitive p was in contact */, rng_counter;
+} solorl_env_state;
+
+typedef struct solorl_env solorl_env;
+
+/* Fills *cfg with the reference's defaults for (robot, task). */
+int solorl_default_config(solorl_config* cfg, int robot, int task);
+
+/* num_envs environments on HIP device `device_id`; `seed` + `env_id_offset` key the per-env
+ * Philox streams (global env id = env_id_offset + i). */
+int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_t seed,
+                  int64_t env_id_offset, solorl_env** out);
+int solorl_destroy(solorl_env* env);
+
+int solorl_dims(const solorl_env* env, int* obs_dim, int* act_dim, int* num_envs);
+
+int solorl_reset(solorl_env* env, float* obs_out /* [N*O] */, void* stream);
+int solorl_step(solorl_env* env, const float* actions /* [N*A] */, float* obs_out /* [N*O] */,
+                float* reward_out /* [N] */, uint8_t* done_out /* [N] */,
+                const solorl_info_soa* info_out /* host struct of device pointers, or NULL */,
+                void* stream);
+int solorl_get_observation(solorl_env* env, float* obs_out, void* stream);
+int solorl_increment_curriculum(solorl_env* env, double value);
+
+int solorl_get_state(solorl_env* env, int env_index, solorl_env_state* out /* host */);
+int solorl_set_state(solorl_env* env, int env_index, const solorl_env_state* in /* host */);
+
+const char* solorl_last_error(void);
+const char* solorl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLORL_H */

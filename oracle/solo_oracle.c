@@ -1,0 +1,606 @@
+/* solo_oracle.c -- TEST INFRASTRUCTURE ONLY (see solo_oracle.h).  "PARITY UNPINNED".
+ *
+ * Plain-C fp64 restatement, one env at a time, of
+ *   SoloBaseEnv.step / reset              reference baseEnv.py:42-82
+ *   SoloBase.apply_action / simulator_step / calc_state / reset   solo.py:166-340
+ *   PD                                    controllers/PD.py:3-10
+ *   worker auto-reset                     agents/ppo/envs.py:36-40
+ *   p.stepSimulation()                    third-party Bullet (absent): restated from its published
+ *                                         btMultiBody design, SURVEY.md Appendix B K1-K11.
+ *
+ * The dynamics are deliberately written in a DIFFERENT formulation from the HIP engine so that
+ * agreement is a real check: here a dense joint-space method (Jacobian-projected Newton-Euler ->
+ * mass matrix M and bias h, Cholesky, M^-1 J^T per constraint row, Bullet-style PGS on generalized
+ * delta-velocities); the HIP engine uses an O(n) articulated-body recursion and a base-space PGS.
+ */
+#include "solo_oracle.h"
+#include "../include/solorl_model_data.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NL_MAX SOLORL_MAX_LINKS
+#define NV_MAX (6 + SOLORL_MAX_DOF)
+#define NP_MAX SOLORL_MAX_PRIMS
+#define MAX_CONTACTS 8    /* engine-wide cap on simultaneously solved contact points */
+#define MAX_LIMITS 2      /* cap on simultaneously solved joint-limit rows */
+#define MAX_ROWS (MAX_LIMITS + 3 * MAX_CONTACTS)
+#define LIMIT_WINDOW 0.5  /* a limit row exists when the joint is within 0.5 rad of +-joint_limit */
+#define DISC_EPS2 1e-12
+
+/* ------------------------------------------------------------------ small algebra */
+static void v3set(double* a, double x, double y, double z) { a[0] = x; a[1] = y; a[2] = z; }
+static void v3cpy(double* a, const double* b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static void v3add(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+static void v3sub(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static void v3axpy(double* r, double s, const double* a) { r[0] += s * a[0]; r[1] += s * a[1]; r[2] += s * a[2]; }
+static double v3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v3norm(const double* a) { return sqrt(v3dot(a, a)); }
+static void v3cross(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void m3mulv(double* r, const double* M, const double* v) { /* row-major */
+  double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void m3tmulv(double* r, const double* M, const double* v) {
+  double x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+  double y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+  double z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void m3mul(double* r, const double* A, const double* B) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(r, t, sizeof t);
+}
+static void quat_to_mat(const double* q, double* R) { /* q = x y z w */
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+static void axis_rot(const double* ax, double ang, double* R) { /* Rodrigues */
+  double c = cos(ang), s = sin(ang), t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
+  R[0] = t * x * x + c;     R[1] = t * x * y - s * z; R[2] = t * x * z + s * y;
+  R[3] = t * x * y + s * z; R[4] = t * y * y + c;     R[5] = t * y * z - s * x;
+  R[6] = t * x * z - s * y; R[7] = t * y * z + s * x; R[8] = t * z * z + c;
+}
+
+/* K10: Bullet btQuaternion::getEulerZYX as returned by p.getEulerFromQuaternion (roll,pitch,yaw) */
+void oracle_euler_from_quat(const double q[4], double rpy[3]) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  double sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  double sarg = -2.0 * (x * z - w * y);
+  if (sarg <= -0.99999) { rpy[1] = -0.5 * M_PI; rpy[0] = 0; rpy[2] = 2 * atan2(x, -y); }
+  else if (sarg >= 0.99999) { rpy[1] = 0.5 * M_PI; rpy[0] = 0; rpy[2] = 2 * atan2(-x, y); }
+  else {
+    rpy[1] = asin(sarg);
+    rpy[0] = atan2(2 * (y * z + w * x), squ - sqx - sqy + sqz);
+    rpy[2] = atan2(2 * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+void oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
+
+/* ------------------------------------------------------------------ model / env */
+struct oracle_env {
+  const solorl_model_data* md;
+  solorl_config cfg;
+  int N, n, nv, nl, np, D, O, nthreads;
+  uint64_t seed; int64_t id0;
+  double goal_radius;
+  double inertia[NL_MAX][6]; /* link inertia about COM in link axes: xx yy zz xy xz yz */
+  solorl_env_state* st;
+  double (*last_lambda)[NP_MAX];
+};
+
+typedef struct {
+  double R[NL_MAX][9], o[NL_MAX][3], c[NL_MAX][3], a[NL_MAX][3];
+  double w[NL_MAX][3], vo[NL_MAX][3], vc[NL_MAX][3];
+  double alb[NL_MAX][3], aob[NL_MAX][3], acb[NL_MAX][3];
+  double Iw[NL_MAX][9];
+} kin_t;
+
+static void kinematics(const oracle_env* E, const solorl_env_state* s, kin_t* K) {
+  const solorl_model_data* md = E->md;
+  quat_to_mat(s->quat, K->R[0]);
+  v3cpy(K->o[0], s->pos);
+  v3cpy(K->w[0], s->ang_vel); v3cpy(K->vo[0], s->lin_vel);
+  v3set(K->alb[0], 0, 0, 0); v3set(K->aob[0], 0, 0, 0); v3set(K->a[0], 0, 0, 0);
+  for (int i = 0; i < E->nl; i++) {
+    const solorl_link_data* L = &md->links[i];
+    if (i > 0) {
+      int p = L->parent;
+      double r[3], t[3], t2[3];
+      m3mulv(r, K->R[p], L->jorigin);             /* o_i - o_p in world */
+      v3add(K->o[i], K->o[p], r);
+      m3mulv(K->a[i], K->R[p], L->axis);          /* world joint axis (zero for fixed) */
+      double qi = 0, qdi = 0;
+      if (L->jtype == 0) { qi = s->q[L->dof]; qdi = s->qd[L->dof]; }
+      if (L->jtype == 0) { double Rj[9]; axis_rot(L->axis, qi, Rj); m3mul(K->R[i], K->R[p], Rj); }
+      else memcpy(K->R[i], K->R[p], sizeof K->R[i]);
+      /* velocities */
+      v3cpy(K->w[i], K->w[p]); v3axpy(K->w[i], qdi, K->a[i]);
+      v3cross(t, K->w[p], r); v3add(K->vo[i], K->vo[p], t);
+      /* bias accelerations (all generalized accelerations zero) */
+      v3cross(t, K->w[p], K->a[i]);
+      v3cpy(K->alb[i], K->alb[p]); v3axpy(K->alb[i], qdi, t);
+      v3cross(t, K->alb[p], r); v3cross(t2, K->w[p], r); v3cross(t2, K->w[p], t2);
+      v3add(K->aob[i], K->aob[p], t); v3add(K->aob[i], K->aob[i], t2);
+    }
+    double rc[3], t[3], t2[3];
+    m3mulv(rc, K->R[i], L->com);
+    v3add(K->c[i], K->o[i], rc);
+    v3cross(t, K->w[i], rc); v3add(K->vc[i], K->vo[i], t);
+    v3cross(t, K->alb[i], rc); v3cross(t2, K->w[i], rc); v3cross(t2, K->w[i], t2);
+    v3add(K->acb[i], K->aob[i], t); v3add(K->acb[i], K->acb[i], t2);
+    /* world inertia about COM: R I R^T */
+    const double* I6 = E->inertia[i];
+    double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]}, Rt[9], T[9];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rt[3 * a + b] = K->R[i][3 * b + a];
+    m3mul(T, K->R[i], Il); m3mul(K->Iw[i], T, Rt);
+  }
+}
+
+/* generalized-force row of a unit force u applied at world point P on link l (= Jacobian row) */
+static void point_jacobian_row(const oracle_env* E, const solorl_env_state* s, const kin_t* K, int l,
+                               const double* P, const double* u, double* row) {
+  double r[3], t[3];
+  for (int k = 0; k < E->nv; k++) row[k] = 0;
+  v3sub(r, P, s->pos); v3cross(t, r, u);
+  row[0] = t[0]; row[1] = t[1]; row[2] = t[2];
+  row[3] = u[0]; row[4] = u[1]; row[5] = u[2];
+  for (int j = l; j > 0; j = E->md->links[j].parent) {
+    const solorl_link_data* L = &E->md->links[j];
+    if (L->jtype != 0) continue;
+    v3sub(r, P, K->o[j]); v3cross(t, r, u);
+    row[6 + L->dof] = v3dot(K->a[j], t);
+  }
+}
+
+static void mass_and_bias(const oracle_env* E, const solorl_env_state* s, const kin_t* K, double* M, double* h) {
+  int nv = E->nv;
+  const double kd = E->cfg.damping;
+  memset(M, 0, sizeof(double) * nv * nv);
+  memset(h, 0, sizeof(double) * nv);
+  for (int i = 0; i < E->nl; i++) {
+    const solorl_link_data* L = &E->md->links[i];
+    double Jv[3][NV_MAX], Jw[3][NV_MAX];
+    memset(Jv, 0, sizeof Jv); memset(Jw, 0, sizeof Jw);
+    double r[3], t[3], e[3];
+    v3sub(r, K->c[i], s->pos);
+    for (int k = 0; k < 3; k++) {
+      v3set(e, k == 0, k == 1, k == 2);
+      v3cross(t, e, r);
+      Jv[0][k] = t[0]; Jv[1][k] = t[1]; Jv[2][k] = t[2];
+      Jv[k][3 + k] = 1; Jw[k][k] = 1;
+    }
+    for (int j = i; j > 0; j = E->md->links[j].parent) {
+      const solorl_link_data* Lj = &E->md->links[j];
+      if (Lj->jtype != 0) continue;
+      v3sub(r, K->c[i], K->o[j]); v3cross(t, K->a[j], r);
+      int col = 6 + Lj->dof;
+      Jv[0][col] = t[0]; Jv[1][col] = t[1]; Jv[2][col] = t[2];
+      Jw[0][col] = K->a[j][0]; Jw[1][col] = K->a[j][1]; Jw[2][col] = K->a[j][2];
+    }
+    for (int a = 0; a < nv; a++)
+      for (int b = 0; b < nv; b++) {
+        double acc = 0;
+        for (int k = 0; k < 3; k++) acc += L->mass * Jv[k][a] * Jv[k][b];
+        for (int k = 0; k < 3; k++)
+          for (int m = 0; m < 3; m++) acc += Jw[k][a] * K->Iw[i][3 * k + m] * Jw[m][b];
+        M[a * nv + b] += acc;
+      }
+    /* link wrench terms: m*a_c^bias - F,   I*alpha^bias + w x I w - T
+     * F = m g + damping (K3: -m v (k + k|v|)),  T = damping (-I w (k + k|w|)) */
+    double F[3], T[3], Iw_w[3], lin[3], ang[3];
+    double vn = v3norm(K->vc[i]), wn = v3norm(K->w[i]);
+    m3mulv(Iw_w, K->Iw[i], K->w[i]);
+    for (int k = 0; k < 3; k++) {
+      F[k] = -L->mass * K->vc[i][k] * (kd + kd * vn);
+      T[k] = -Iw_w[k] * (kd + kd * wn);
+    }
+    F[2] += -L->mass * E->cfg.gravity;
+    m3mulv(ang, K->Iw[i], K->alb[i]);
+    v3cross(t, K->w[i], Iw_w);                       /* gyroscopic term (K1) */
+    for (int k = 0; k < 3; k++) { lin[k] = L->mass * K->acb[i][k] - F[k]; ang[k] += t[k] - T[k]; }
+    for (int a = 0; a < nv; a++)
+      for (int k = 0; k < 3; k++) h[a] += Jv[k][a] * lin[k] + Jw[k][a] * ang[k];
+  }
+}
+
+static int cholesky(double* A, int n) { /* in place, lower */
+  for (int j = 0; j < n; j++) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0)) return -1;
+    d = sqrt(d); A[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double v = A[i * n + j];
+      for (int k = 0; k < j; k++) v -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = v / d;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double* Lm, int n, const double* b, double* x) {
+  double y[NV_MAX];
+  for (int i = 0; i < n; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= Lm[i * n + k] * y[k]; y[i] = v / Lm[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < n; k++) v -= Lm[k * n + i] * x[k]; x[i] = v / Lm[i * n + i]; }
+}
+
+/* world support point of primitive p towards the ground, and its height above z=0 */
+static double prim_point(const oracle_env* E, const kin_t* K, int p, double* P) {
+  const solorl_prim_data* pr = &E->md->prims[p];
+  int l = pr->link;
+  double loc[3]; v3cpy(loc, pr->center);
+  if (pr->axis >= 0) {
+    double up[3] = {0, 0, 1}, d[3];
+    m3tmulv(d, K->R[l], up);
+    for (int k = 0; k < 3; k++) d[k] = -d[k];           /* world down in link axes */
+    d[pr->axis] = 0;                                     /* project off the disc axis */
+    double inv = pr->radius / sqrt(v3dot(d, d) + DISC_EPS2);
+    v3axpy(loc, inv, d);
+  }
+  m3mulv(P, K->R[l], loc); v3add(P, P, K->o[l]);
+  return P[2];
+}
+
+typedef struct { double J[NV_MAX], B[NV_MAX], rhs, dinv, lam, mu; int parent; /* -1: lo=0,hi=inf */ } row_t;
+
+static void clampv(double* v, double lim) { if (*v > lim) *v = lim; if (*v < -lim) *v = -lim; }
+
+static void substep(oracle_env* E, int ei) {
+  solorl_env_state* s = &E->st[ei];
+  const solorl_config* C = &E->cfg;
+  const int nv = E->nv, n = E->n;
+  const double dt = C->sim_dt;
+  kin_t K;
+  kinematics(E, s, &K);
+
+  /* --- collision detection at the start-of-step pose (K1, K6') */
+  int act[NP_MAX], nact = 0; double P[NP_MAX][3], dist[NP_MAX];
+  for (int p = 0; p < E->np; p++) {
+    dist[p] = prim_point(E, &K, p, P[p]);
+    if (dist[p] < E->md->prims[p].margin) act[nact++] = p;
+  }
+  if (nact > MAX_CONTACTS) { /* keep the MAX_CONTACTS deepest (ties: lower primitive id) */
+    int keep[NP_MAX] = {0};
+    for (int a = 0; a < nact; a++) {
+      int rank = 0;
+      for (int b = 0; b < nact; b++)
+        if (dist[act[b]] < dist[act[a]] || (dist[act[b]] == dist[act[a]] && act[b] < act[a])) rank++;
+      keep[a] = rank < MAX_CONTACTS;
+    }
+    int m = 0;
+    for (int a = 0; a < nact; a++) if (keep[a]) act[m++] = act[a];
+    nact = m;
+  }
+
+  /* --- unconstrained forward dynamics: u* = u + dt M^-1 (tau - h)  (K1) */
+  double M[NV_MAX * NV_MAX], h[NV_MAX], rhsv[NV_MAX], udot[NV_MAX], u[NV_MAX];
+  mass_and_bias(E, s, &K, M, h);
+  cholesky(M, nv);
+  for (int k = 0; k < 6; k++) rhsv[k] = -h[k];
+  for (int j = 0; j < n; j++) rhsv[6 + j] = s->tau[j] - h[6 + j];
+  chol_solve(M, nv, rhsv, udot);
+  for (int k = 0; k < 3; k++) { u[k] = s->ang_vel[k]; u[3 + k] = s->lin_vel[k]; }
+  for (int j = 0; j < n; j++) u[6 + j] = s->qd[j];
+  for (int k = 0; k < nv; k++) { u[k] += dt * udot[k]; clampv(&u[k], C->max_velocity); } /* K5 */
+
+  /* --- constraint rows: joint limits, contact normals, friction (K7) */
+  row_t rows[MAX_ROWS]; int nr = 0, nlim = 0;
+  for (int j = 0; j < n && nlim < MAX_LIMITS; j++) {
+    for (int side = 0; side < 2 && nlim < MAX_LIMITS; side++) {
+      double pen = side == 0 ? s->q[j] + C->joint_limit : C->joint_limit - s->q[j];
+      if (!(pen < LIMIT_WINDOW)) continue;
+      row_t* r = &rows[nr++]; nlim++;
+      memset(r, 0, sizeof *r);
+      r->J[6 + j] = side == 0 ? 1.0 : -1.0; r->parent = -1; r->mu = 0;
+      r->rhs = pen; /* stash penetration; finished below */
+    }
+  }
+  int normal_row[NP_MAX];
+  for (int a = 0; a < nact; a++) {
+    int p = act[a];
+    double nrm[3] = {0, 0, 1};
+    row_t* r = &rows[nr]; memset(r, 0, sizeof *r);
+    point_jacobian_row(E, s, &K, E->md->prims[p].link, P[p], nrm, r->J);
+    r->parent = -1; r->rhs = dist[p] + C->linear_slop; normal_row[a] = nr++;
+  }
+  int nnormal_end = nr;
+  for (int a = 0; a < nact; a++) {
+    int p = act[a];
+    for (int d = 0; d < 2; d++) {
+      double t[3] = {d == 0, d == 1, 0};
+      row_t* r = &rows[nr++]; memset(r, 0, sizeof *r);
+      point_jacobian_row(E, s, &K, E->md->prims[p].link, P[p], t, r->J);
+      r->parent = normal_row[a]; r->mu = E->md->prims[p].friction;
+    }
+  }
+  double dV[NV_MAX]; memset(dV, 0, sizeof dV);
+  for (int i = 0; i < nr; i++) {
+    row_t* r = &rows[i];
+    chol_solve(M, nv, r->J, r->B);
+    double denom = 0, rel = 0;
+    for (int k = 0; k < nv; k++) { denom += r->J[k] * r->B[k]; rel += r->J[k] * u[k]; }
+    r->dinv = 1.0 / denom;
+    if (i < nnormal_end) { /* limit or normal row: speculative / ERP right-hand side */
+      double pen = r->rhs, pos = 0, vel = -rel;
+      if (pen > 0) vel -= pen / dt; else pos = -pen * C->erp / dt;
+      r->rhs = (pos + vel) * r->dinv;
+    } else r->rhs = -rel * r->dinv;
+    r->lam = 0;
+  }
+  for (int a = 0; a < nact; a++) { /* warm start cached normal impulses */
+    row_t* r = &rows[normal_row[a]];
+    r->lam = C->warmstart * s->lambda_prev[act[a]];
+    for (int k = 0; k < nv; k++) dV[k] += r->B[k] * r->lam;
+  }
+  for (int it = 0; it < C->solver_iterations; it++) {
+    for (int i = 0; i < nr; i++) {
+      row_t* r = &rows[i];
+      double jdv = 0;
+      for (int k = 0; k < nv; k++) jdv += r->J[k] * dV[k];
+      double delta = r->rhs - jdv * r->dinv, sum = r->lam + delta, lo = 0, hi = 1e30;
+      if (r->parent >= 0) { hi = r->mu * rows[r->parent].lam; lo = -hi; }
+      if (sum < lo) sum = lo; if (sum > hi) sum = hi;
+      delta = sum - r->lam; r->lam = sum;
+      for (int k = 0; k < nv; k++) dV[k] += r->B[k] * delta;
+    }
+  }
+  for (int k = 0; k < nv; k++) { u[k] += dV[k]; clampv(&u[k], C->max_velocity); }
+  for (int p = 0; p < E->np; p++) { s->lambda_prev[p] = 0; E->last_lambda[ei][p] = 0; }
+  s->contact_mask = 0;
+  for (int a = 0; a < nact; a++) {
+    s->lambda_prev[act[a]] = rows[normal_row[a]].lam;
+    E->last_lambda[ei][act[a]] = rows[normal_row[a]].lam;
+    s->contact_mask |= 1 << act[a];
+  }
+
+  /* --- semi-implicit Euler position update with the new velocities (K1) */
+  for (int k = 0; k < 3; k++) { s->ang_vel[k] = u[k]; s->lin_vel[k] = u[3 + k]; s->pos[k] += dt * u[3 + k]; }
+  for (int j = 0; j < n; j++) { s->qd[j] = u[6 + j]; s->q[j] += dt * u[6 + j]; }
+  {
+    double wn = v3norm(s->ang_vel), sc, cw;
+    if (wn < 1e-3) sc = 0.5 * dt - dt * dt * dt * (1.0 / 48.0) * wn * wn; else sc = sin(0.5 * wn * dt) / wn;
+    cw = cos(0.5 * wn * dt);
+    double ax = s->ang_vel[0] * sc, ay = s->ang_vel[1] * sc, az = s->ang_vel[2] * sc;
+    double x = s->quat[0], y = s->quat[1], z = s->quat[2], w = s->quat[3];
+    double nx = cw * x + ax * w + ay * z - az * y;   /* dq (x) q */
+    double ny = cw * y - ax * z + ay * w + az * x;
+    double nz = cw * z + ax * y - ay * x + az * w;
+    double nw = cw * w - ax * x - ay * y - az * z;
+    double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+    s->quat[0] = nx * inv; s->quat[1] = ny * inv; s->quat[2] = nz * inv; s->quat[3] = nw * inv;
+  }
+  if (!C->hold_torque) for (int j = 0; j < n; j++) s->tau[j] = 0;   /* K8: cleared after every stepSimulation */
+}
+
+/* ------------------------------------------------------------------ env logic */
+static int foot_contact(const oracle_env* E, const solorl_env_state* s, int f) {
+  return (s->contact_mask >> E->md->foot_prim[f]) & 1;
+}
+
+/* SoloBase.get_current_state, reference solo.py:198-222 */
+static void current_state(const oracle_env* E, const solorl_env_state* s, double* out) {
+  int k = 0, n = E->n;
+  double rpy[3];
+  out[k++] = s->pos[2];
+  oracle_euler_from_quat(s->quat, rpy);
+  for (int i = 0; i < 3; i++) { double e = rpy[i]; e = e - 2.0 * floor(e / 2.0); out[k++] = e / 2.0; } /* (e % 2*pi)/(2*pi), solo.py:206 */
+  for (int i = 0; i < 3; i++) out[k++] = s->lin_vel[i];
+  for (int i = 0; i < 3; i++) out[k++] = s->ang_vel[i];
+  for (int j = 0; j < n; j++) out[k++] = s->q[j] / E->cfg.joint_limit;
+  for (int j = 0; j < n; j++) out[k++] = s->qd[j] / 100.0;           /* solo.py:110 joint_vel_limit */
+  for (int f = 0; f < 4; f++) out[k++] = foot_contact(E, s, f) ? 1.0 : 0.0;
+  if (E->cfg.task == SOLORL_TASK_POINTGOAL) {
+    out[k++] = s->pos[0] / 2; out[k++] = s->pos[1] / 2; out[k++] = s->goal[0] / 2; out[k++] = s->goal[1] / 2;
+  }
+}
+/* SoloBase.calc_state, solo.py:186-196 */
+static void calc_state(const oracle_env* E, const solorl_env_state* s, double* obs) {
+  current_state(E, s, obs);
+  for (int hI = 0; hI < E->cfg.num_history_stack; hI++)
+    for (int k = 0; k < E->D; k++) obs[(hI + 1) * E->D + k] = obs[k] - s->hist[hI][k];
+}
+static void push_history(const oracle_env* E, solorl_env_state* s) {
+  int H = E->cfg.num_history_stack;
+  if (H == 0) return;
+  double cur[SOLORL_STATE_MAX_OBS];
+  current_state(E, s, cur);
+  for (int hI = H - 1; hI > 0; hI--) memcpy(s->hist[hI], s->hist[hI - 1], sizeof(double) * E->D);
+  memcpy(s->hist[0], cur, sizeof(double) * E->D);
+}
+static void sample_goal(const oracle_env* E, int gi, solorl_env_state* s) { /* solo.py:325-330 */
+  uint32_t r[4];
+  uint64_t gid = (uint64_t)(E->id0 + gi);
+  oracle_philox((uint32_t)E->seed, (uint32_t)(E->seed >> 32), (uint32_t)gid, (uint32_t)(gid >> 32),
+                (uint32_t)s->rng_counter++, 1u, r);
+  double x = 1.0 + u01(r[0]) * (E->goal_radius - 1.0), y = 1.0 + u01(r[1]) * (E->goal_radius - 1.0);
+  s->goal[0] = (r[2] & 1u) ? x : -x; s->goal[1] = (r[3] & 1u) ? y : -y;
+}
+static double potential(const solorl_env_state* s) {
+  double dx = s->pos[0] - s->goal[0], dy = s->pos[1] - s->goal[1];
+  return sqrt(dx * dx + dy * dy);
+}
+/* SoloBase.simulator_step, solo.py:261-274 */
+static void simulator_step(oracle_env* E, int i) {
+  solorl_env_state* s = &E->st[i];
+  push_history(E, s);
+  for (int k = 0; k < E->cfg.frame_skip; k++) substep(E, i);
+  for (int j = 0; j < E->n; j++) s->tau[j] = 0;   /* hold_torque=1 holds it for this control step only */
+  if (E->cfg.task == SOLORL_TASK_POINTGOAL) {
+    double old = s->potential;
+    s->potential = potential(s);
+    s->progress = -(s->potential - old);
+    if (s->potential < 0.5) { s->goals_reached += 1; sample_goal(E, i, s); }
+  }
+}
+/* SoloBaseEnv.reset, baseEnv.py:70-82 (+ SoloBase.reset solo.py:166-181, :291-296) */
+static void env_reset(oracle_env* E, int i) {
+  solorl_env_state* s = &E->st[i];
+  int rc = s->rng_counter;
+  double g0 = s->goal[0], g1 = s->goal[1];
+  memset(s, 0, sizeof *s);
+  s->rng_counter = rc; s->goal[0] = g0; s->goal[1] = g1;
+  s->pos[2] = 0.35; s->quat[3] = 1.0;                  /* solo.py:52,292-293 */
+  for (int hI = 0; hI < E->cfg.num_history_stack; hI++) current_state(E, s, s->hist[hI]);
+  if (E->cfg.task == SOLORL_TASK_POINTGOAL) {
+    sample_goal(E, i, s);   /* after the history fill, as solo.py:170-174: history keeps the old goal */
+    s->goals_reached = 0; s->potential = potential(s); s->progress = 0;
+  }
+  uint32_t r[4];
+  uint64_t gid = (uint64_t)(E->id0 + i);
+  oracle_philox((uint32_t)E->seed, (uint32_t)(E->seed >> 32), (uint32_t)gid, (uint32_t)(gid >> 32),
+                (uint32_t)s->rng_counter++, 2u, r);
+  int K = E->cfg.settle_min + (int)(r[0] % (uint32_t)(E->cfg.settle_max - E->cfg.settle_min + 1));
+  for (int k = 0; k < K; k++) simulator_step(E, i);
+}
+
+static void apply_action(const oracle_env* E, solorl_env_state* s, const double* a) { /* solo.py:224-259 */
+  for (int j = 0; j < E->n; j++) {
+    double c = a[j] < -1 ? -1 : (a[j] > 1 ? 1 : a[j]);
+    if (E->cfg.control == SOLORL_CONTROL_TORQUE) s->tau[j] = c * E->cfg.max_torque;
+    else {
+      double qref = c * E->cfg.joint_limit;
+      double t = E->cfg.kp * (qref - s->q[j]) - E->cfg.kd * s->qd[j];   /* controllers/PD.py:5 */
+      if (t > E->cfg.max_torque) t = E->cfg.max_torque; if (t < -E->cfg.max_torque) t = -E->cfg.max_torque;
+      s->tau[j] = t;
+    }
+  }
+}
+
+static void env_step(oracle_env* E, int i, const double* a, double* obs, double* rew, uint8_t* done,
+                     uint8_t* timeout, uint8_t* success, int32_t* ep_len, double* ep_rew, double* goals, double* dr) {
+  solorl_env_state* s = &E->st[i];
+  const solorl_config* C = &E->cfg;
+  int n = E->n;
+  apply_action(E, s, a);
+  simulator_step(E, i);
+  s->timestep += 1;
+  /* reward, baseEnv.py:91-157 */
+  double z = s->pos[2];
+  double stand = (z > 0.2) ? 0.5 : 0.0, jp = 0, balance = 0, progress = 0, torque = 0;
+  for (int j = 0; j < n; j++) jp += (C->task == SOLORL_TASK_STAND) ? fabs(s->q[j]) : s->q[j] * s->q[j];
+  jp = -0.1 * jp / n;
+  if (C->task == SOLORL_TASK_WALK) {
+    if (z > 0.2) { double vx = s->lin_vel[0]; progress = 2.0 * ((vx > 0) - (vx < 0)) * vx * vx; }
+  } else if (C->task == SOLORL_TASK_POINTGOAL) {
+    double rpy[3]; oracle_euler_from_quat(s->quat, rpy);
+    balance = -0.1 * (fabs(rpy[0]) + fabs(rpy[1]));
+    if (z > 0.2) progress = s->progress * (1.0 / C->reward_dt);
+  }
+  if (C->control == SOLORL_CONTROL_TORQUE) { double tp = 0; for (int j = 0; j < n; j++) tp += a[j] * a[j]; torque = -0.01 * tp; }
+  double reward = stand + jp + balance + progress + torque;
+  s->dr[0] += stand; s->dr[1] += jp; s->dr[2] += torque; s->dr[3] += balance; s->dr[4] += progress;
+  /* termination, baseEnv.py:162-180 */
+  int d = 0, to = 0, su = 0;
+  if (!C->disable_termination) {
+    if (s->timestep >= C->episode_length) { d = 1; to = 1; su = C->task != SOLORL_TASK_POINTGOAL; }
+    else if (z < 0.05) { d = 1; }
+    else if (C->task == SOLORL_TASK_POINTGOAL && s->goals_reached > s->env_goals_reached) {
+      s->env_goals_reached = s->goals_reached; d = 1; su = 1;
+    }
+  }
+  if (d) { /* baseEnv.py:52-60 */
+    if (su) { if (C->task == SOLORL_TASK_POINTGOAL) reward = 0.1 * (C->episode_length - s->timestep); }
+    else if (!to) reward = -10.0;
+  }
+  if (rew) rew[i] = reward;
+  if (done) done[i] = (uint8_t)d;
+  if (timeout) timeout[i] = (uint8_t)to;
+  if (success) success[i] = (uint8_t)su;
+  if (ep_len) ep_len[i] = s->timestep;
+  if (ep_rew) ep_rew[i] = reward;
+  if (goals) goals[i] = s->env_goals_reached;
+  if (dr) for (int k = 0; k < 5; k++) dr[5 * i + k] = s->dr[k];
+  if (d) env_reset(E, i);                               /* agents/ppo/envs.py:39 */
+  calc_state(E, s, obs + (size_t)i * E->O);
+}
+
+/* ------------------------------------------------------------------ public API */
+oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed, int64_t env_id_offset) {
+  oracle_env* E = (oracle_env*)calloc(1, sizeof *E);
+  E->cfg = *cfg;
+  E->md = cfg->robot == SOLORL_ROBOT_SOLO12 ? &SOLORL_MODEL_SOLO12 : &SOLORL_MODEL_SOLO8;
+  E->N = num_envs; E->n = E->md->ndof; E->nv = 6 + E->n; E->nl = E->md->nlinks; E->np = E->md->nprims;
+  E->D = 14 + 2 * E->n + (cfg->task == SOLORL_TASK_POINTGOAL ? 4 : 0);
+  E->O = E->D * (1 + cfg->num_history_stack);
+  E->seed = seed; E->id0 = env_id_offset; E->goal_radius = cfg->goal_radius; E->nthreads = 1;
+  for (int i = 0; i < E->nl; i++) {
+    const solorl_link_data* L = &E->md->links[i];
+    if (cfg->use_urdf_inertia) memcpy(E->inertia[i], L->inertia_urdf, sizeof(double) * 6);
+    else { E->inertia[i][0] = L->inertia_box[0]; E->inertia[i][1] = L->inertia_box[1]; E->inertia[i][2] = L->inertia_box[2]; }
+  }
+  E->st = (solorl_env_state*)calloc((size_t)num_envs, sizeof *E->st);
+  E->last_lambda = calloc((size_t)num_envs, sizeof *E->last_lambda);
+  for (int i = 0; i < num_envs; i++) { E->st[i].quat[3] = 1; E->st[i].pos[2] = 0.35; E->st[i].need_reset = 1; }
+  return E;
+}
+void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E); }
+void oracle_dims(const oracle_env* E, int* o, int* a, int* n) { if (o) *o = E->O; if (a) *a = E->n; if (n) *n = E->N; }
+void oracle_set_threads(oracle_env* E, int t) { E->nthreads = t < 1 ? 1 : t; }
+void oracle_reset(oracle_env* E, double* obs) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(E->nthreads)
+  for (int i = 0; i < E->N; i++) { env_reset(E, i); E->st[i].need_reset = 0; calc_state(E, &E->st[i], obs + (size_t)i * E->O); }
+}
+void oracle_step(oracle_env* E, const double* actions, double* obs, double* rew, uint8_t* done, uint8_t* timeout,
+                 uint8_t* success, int32_t* ep_len, double* ep_rew, double* goals, double* dr) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(E->nthreads)
+  for (int i = 0; i < E->N; i++)
+    env_step(E, i, actions + (size_t)i * E->n, obs, rew, done, timeout, success, ep_len, ep_rew, goals, dr);
+}
+void oracle_get_observation(oracle_env* E, double* obs) {
+  for (int i = 0; i < E->N; i++) calc_state(E, &E->st[i], obs + (size_t)i * E->O);
+}
+void oracle_increment_curriculum(oracle_env* E, double v) { if (E->cfg.task == SOLORL_TASK_POINTGOAL) E->goal_radius += v; }
+void oracle_get_state(const oracle_env* E, int i, solorl_env_state* out) { *out = E->st[i]; }
+void oracle_set_state(oracle_env* E, int i, const solorl_env_state* in) { E->st[i] = *in; }
+void oracle_substep(oracle_env* E, int i) { substep(E, i); }
+void oracle_mass_matrix(const oracle_env* E, int i, double* M, double* h) {
+  kin_t K; kinematics(E, &E->st[i], &K); mass_and_bias(E, &E->st[i], &K, M, h);
+}
+void oracle_forward_dynamics(const oracle_env* E, int i, double* udot) {
+  double M[NV_MAX * NV_MAX], h[NV_MAX], r[NV_MAX];
+  oracle_mass_matrix(E, i, M, h);
+  cholesky(M, E->nv);
+  for (int k = 0; k < 6; k++) r[k] = -h[k];
+  for (int j = 0; j < E->n; j++) r[6 + j] = E->st[i].tau[j] - h[6 + j];
+  chol_solve(M, E->nv, r, udot);
+}
+void oracle_energy_momentum(const oracle_env* E, int i, double* out) {
+  kin_t K; kinematics(E, &E->st[i], &K);
+  double T = 0, V = 0, p[3] = {0, 0, 0}, Lm[3] = {0, 0, 0};
+  for (int l = 0; l < E->nl; l++) {
+    double m = E->md->links[l].mass, Iw[3], t[3];
+    m3mulv(Iw, K.Iw[l], K.w[l]);
+    T += 0.5 * m * v3dot(K.vc[l], K.vc[l]) + 0.5 * v3dot(K.w[l], Iw);
+    V += m * E->cfg.gravity * K.c[l][2];
+    v3axpy(p, m, K.vc[l]);
+    v3cross(t, K.c[l], K.vc[l]); v3axpy(Lm, m, t); v3add(Lm, Lm, Iw);
+  }
+  out[0] = T; out[1] = V; memcpy(out + 2, p, sizeof p); memcpy(out + 5, Lm, sizeof Lm);
+}
+void oracle_prim_points(const oracle_env* E, int i, double* out) {
+  kin_t K; kinematics(E, &E->st[i], &K);
+  for (int p = 0; p < E->np; p++) { double P[3]; out[4 * p + 3] = prim_point(E, &K, p, P); memcpy(out + 4 * p, P, sizeof P); }
+}
+void oracle_last_lambda(const oracle_env* E, int i, double* lam) { memcpy(lam, E->last_lambda[i], sizeof(double) * E->np); }

@@ -1,0 +1,59 @@
+/* solo_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * fp64 CPU restatement of the reference hot path (SoloBaseEnv.step/reset over PyBullet).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product path
+ * (solorl_amd/, libsolorl_hip.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the physics lives in the un-vendored, un-pinned third-party `pybullet`
+ * (reference README.md:4-8; call sites solo.py:66,265), which is absent here, and the reference
+ * holds no tests or golden vectors for this path.  The restatement follows Bullet's
+ * published btMultiBody algorithm (deviations listed in DESIGN.md)
+ * and is pinned by physics known-answer tests (tests/test_oracle_physics.py) instead.
+ */
+#ifndef SOLO_ORACLE_H
+#define SOLO_ORACLE_H
+#include "../include/solorl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_env oracle_env;
+
+oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed, int64_t env_id_offset);
+void oracle_destroy(oracle_env* e);
+void oracle_dims(const oracle_env* e, int* obs_dim, int* act_dim, int* num_envs);
+void oracle_reset(oracle_env* e, double* obs_out);
+/* info arrays may be NULL; layout as solorl_info_soa but double/int32 host arrays */
+void oracle_step(oracle_env* e, const double* actions, double* obs_out, double* rew_out,
+                 uint8_t* done_out, uint8_t* timeout, uint8_t* success, int32_t* ep_len,
+                 double* ep_rew, double* goals, double* dr /* [N*5] */);
+void oracle_get_observation(oracle_env* e, double* obs_out);
+void oracle_increment_curriculum(oracle_env* e, double value);
+void oracle_get_state(const oracle_env* e, int i, solorl_env_state* out);
+void oracle_set_state(oracle_env* e, int i, const solorl_env_state* in);
+void oracle_set_threads(oracle_env* e, int nthreads);
+
+/* ---- low-level hooks for the physics known-answer tests ---- */
+/* one physics sub-step of env i (tau from its state; cleared afterwards unless hold_torque) */
+void oracle_substep(oracle_env* e, int i);
+/* mass matrix M [nv*nv] and bias h [nv] (gravity, Coriolis/gyroscopic, damping) of env i;
+ * generalized velocity order: base angular (world), base linear (world), joint rates */
+void oracle_mass_matrix(const oracle_env* e, int i, double* M, double* h);
+/* unconstrained accelerations udot [nv] = M^-1 (tau - h) */
+void oracle_forward_dynamics(const oracle_env* e, int i, double* udot);
+/* kinetic, potential energy; linear momentum[3]; angular momentum about world origin[3] */
+void oracle_energy_momentum(const oracle_env* e, int i, double* out8);
+/* world position of link origin/com and world point+distance of each primitive: out[np*4] */
+void oracle_prim_points(const oracle_env* e, int i, double* out);
+/* last solve of env i: number of rows, and per active primitive the normal impulse */
+void oracle_last_lambda(const oracle_env* e, int i, double* lambda_n /* [nprims] */);
+/* Philox4x32-10 (for RNG parity tests) */
+void oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                   uint32_t out[4]);
+void oracle_euler_from_quat(const double q[4], double rpy[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
