@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the hot path on N GPUs of one node.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
+rank per GPU).  A "step" = one pass of the hot path over one batch: solorl_step() on 4096
+Solo12 'walk' envs per GPU (configs/basic12.yaml with task overridden to walk: frame_skip 4,
+episode_length 400, num_history_stack 1, torque control) driven by a random policy
+(a ~ U(-1,1)^12, synthetic, resident in HBM before the timed region).  Envs shard across ranks with no
+data-path collective ("weak" scaling); the only collectives are the barrier and the max-reduce
+of the elapsed time the contract asks for.
+
+Prints ONE JSON line with value = whole-job env-steps/s plus `roofline` (algorithmic bytes of
+SURVEY.md 8d / kernel time from HIP events on the launch stream) and `cpu_baseline` (the fp64
+oracle timed on the host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(A, S, C, O, hist_state, n_dr=5, n_counters=2):
+    """B = 4*(A + 2S + 2C + O + H_rw + 2) + 1."""
+    h_rw = 2 * (hist_state + n_dr + n_counters)
+    return 4 * (A + 2 * S + 2 * C + O + h_rw + 2) + 1
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """Oracle (fp64 CPU restatement, kind 'port') on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle.oracle_py import Oracle
+    cores = os.cpu_count() or 1
+    N = 16 * cores
+    orc = Oracle(cfg, N, seed=1, threads=cores)
+    orc.reset()
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(8, N, orc.A))
+    orc.step(acts[0])
+    t0 = time.perf_counter(); steps = 0
+    while True:
+        orc.step(acts[steps % 8]); steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 2000:
+            break
+    return {"value": N * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d Solo12-walk envs x %d control steps, random policy, OpenMP over envs (%.1f s)" % (N, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from solorl_amd.config import default_config, ROBOT_SOLO12, TASK_WALK
+    from solorl_amd.vec_env import SoloVecEnv
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N = args.envs_per_gpu
+    cfg = default_config(ROBOT_SOLO12, TASK_WALK)
+    cfg.num_history_stack = 1                      # configs/basic12.yaml
+    env = SoloVecEnv(cfg, N, device=dev, seed=1, env_id_offset=rank * N)
+    env.reset()
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    R = 64
+    acts = torch.rand((R, N, env.act_dim), device=dev, generator=g) * 2 - 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        env.step_inplace(acts[t % R])
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        env.step_inplace(acts[t % R])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    # kernel time from HIP events on the launch stream (the engine launches on torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
+    for t, (a, b) in enumerate(ev):
+        a.record(); env.step_inplace(acts[t % R]); b.record()
+    torch.cuda.synchronize()
+    kms = sorted(a.elapsed_time(b) for a, b in ev)
+    k_avg = sum(kms) / len(kms)
+
+    if rank == 0:
+        A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
+        bytes_step = algorithmic_bytes_per_env_step(A=A, S=S, C=48, O=O, hist_state=D)
+        achieved = bytes_step * N / (k_avg * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/s (whole node) Solo12 walk, 4096 envs/GPU",
+            "value": world * N * args.steps / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "solo12_walk_%denvs_per_gpu_random_policy_sim_only" % N, "robot": "solo12",
+                       "task": "walk", "envs_per_gpu": N, "frame_skip": 4, "episode_length": 400,
+                       "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step_kernel<float,solo12,64>", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
+                         "algorithmic_bytes_per_env_step": bytes_step,
+                         "note": "path is FP32-VALU/latency bound (SURVEY 8d); HBM fraction is small by construction"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,648 @@
+// solorl_hip.hip -- gfx950 kernels + the C ABI of include/solorl.h.
+//
+// Hot path: one launch of `step_kernel` = SoloBaseEnv.step for every env
+// (reference baseEnv.py:42-68) INCLUDING the worker's auto-reset (agents/ppo/envs.py:38-40):
+//   A3 apply_action (solo.py:224-259, controllers/PD.py:3-10)  -> A4 simulator_step (solo.py:261-274:
+//   history push, frame_skip x physics sub-step, pointgoal progress) -> A6 observation
+//   (solo.py:186-222) -> A7 reward (baseEnv.py:91-157) -> A8 termination (baseEnv.py:162-180)
+//   -> A1 terminal reward override / info (baseEnv.py:52-66) -> A2/A9 reset (baseEnv.py:70-82).
+//
+// Layout: one env per lane, 64 envs per workgroup (one wavefront), struct-of-arrays state in HBM
+// (field-major: every load/store of a field is one coalesced 256-byte access per wave), constraint
+// rows of the contact solve in LDS, everything else in VGPRs.
+//
+// Reset is O(1): `reset = fixed pose + K zero-torque control steps` is a pure function of K
+// (5..11), so the post-settle states are simulated ONCE at create time by this same kernel
+// (mode = SETTLE) into a snapshot table and a terminating lane just loads snapshot[K].
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/solorl.h"
+#include "dynamics.hpp"
+
+using namespace solo;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SOLORL_ERR_HIP, std::string(#x ": ") + hipGetErrorString(e_)); } while (0)
+
+constexpr int DMAX = SOLORL_STATE_MAX_OBS;   // 42
+
+// field-major state layout (offsets in units of N elements)
+struct Layout {
+  int n, D, H, NF;
+  int pos, quat, v, w, q, qd, lam, hist, goal, pot, prog, goals, egoals, dr, xyprev;
+};
+enum { I_TIMESTEP = 0, I_MASK = 1, I_RNG = 2, I_NEEDRESET = 3, NI = 4 };
+
+Layout make_layout(int n, int D, int H) {
+  Layout L; int o = 0;
+  L.n = n; L.D = D; L.H = H;
+  L.pos = o; o += 3; L.quat = o; o += 4; L.v = o; o += 3; L.w = o; o += 3;
+  L.q = o; o += n; L.qd = o; o += n; L.lam = o; o += NPRIM; L.hist = o; o += 2 * DMAX;
+  L.goal = o; o += 2; L.pot = o++; L.prog = o++; L.goals = o++; L.egoals = o++; L.dr = o; o += 5; L.xyprev = o; o += 2;
+  L.NF = o;
+  return L;
+}
+
+struct EnvParams {
+  int task, control, frame_skip, episode_length, hold_torque, disable_termination;
+  int settle_min, nsettle;
+  unsigned seed_lo, seed_hi; long long id0;
+  double kp, kd, max_torque, reward_dt, goal_radius;
+};
+
+enum { MODE_STEP = 0, MODE_SETTLE = 1 };
+
+struct Outputs {
+  float* obs; float* rew; unsigned char* done;
+  unsigned char *timeout, *success, *nan_reset; int* ep_len; float *ep_rew, *goals, *dr0, *dr1, *dr2, *dr3, *dr4;
+};
+
+// ---------------------------------------------------------------- device helpers
+SD void philox(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Bullet getEulerZYX (K10), as returned by p.getEulerFromQuaternion: roll, pitch, yaw
+template <typename T> SD void euler_zyx(T x, T y, T z, T w, T& roll, T& pitch, T& yaw) {
+  T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  T sarg = T(-2) * (x * z - w * y);
+  if (sarg <= T(-0.99999)) { pitch = T(-0.5 * M_PI); roll = T(0); yaw = T(2) * atan2(x, -y); }
+  else if (sarg >= T(0.99999)) { pitch = T(0.5 * M_PI); roll = T(0); yaw = T(2) * atan2(-x, y); }
+  else {
+    pitch = asin(sarg);
+    roll = atan2(T(2) * (y * z + w * x), squ - sqx - sqy + sqz);
+    yaw = atan2(T(2) * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+}
+
+template <typename T, int NQ> struct Env {
+  PhysState<T, NQ> ps;
+  T goal[2], pot, prog, goals, egoals, dr[5], xyprev[2];
+  int timestep, mask, rng;
+};
+
+template <typename T, int NQ>
+SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, size_t N, size_t e) {
+  auto F = [&](int f) { return sf[(size_t)f * N + e]; };
+  E.ps.pos = mk(F(L.pos), F(L.pos + 1), F(L.pos + 2));
+  E.ps.qx = F(L.quat); E.ps.qy = F(L.quat + 1); E.ps.qz = F(L.quat + 2); E.ps.qw = F(L.quat + 3);
+  E.ps.v = mk(F(L.v), F(L.v + 1), F(L.v + 2)); E.ps.w = mk(F(L.w), F(L.w + 1), F(L.w + 2));
+#pragma unroll
+  for (int j = 0; j < NQ; j++) { E.ps.q[j] = F(L.q + j); E.ps.qd[j] = F(L.qd + j); }
+  E.goal[0] = F(L.goal); E.goal[1] = F(L.goal + 1); E.pot = F(L.pot); E.prog = F(L.prog);
+  E.goals = F(L.goals); E.egoals = F(L.egoals);
+#pragma unroll
+  for (int k = 0; k < 5; k++) E.dr[k] = F(L.dr + k);
+  E.xyprev[0] = F(L.xyprev); E.xyprev[1] = F(L.xyprev + 1);
+  E.timestep = si[(size_t)I_TIMESTEP * N + e]; E.mask = si[(size_t)I_MASK * N + e]; E.rng = si[(size_t)I_RNG * N + e];
+}
+template <typename T, int NQ>
+SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, size_t N, size_t e) {
+  auto F = [&](int f, T v) { sf[(size_t)f * N + e] = v; };
+  F(L.pos, E.ps.pos.x); F(L.pos + 1, E.ps.pos.y); F(L.pos + 2, E.ps.pos.z);
+  F(L.quat, E.ps.qx); F(L.quat + 1, E.ps.qy); F(L.quat + 2, E.ps.qz); F(L.quat + 3, E.ps.qw);
+  F(L.v, E.ps.v.x); F(L.v + 1, E.ps.v.y); F(L.v + 2, E.ps.v.z);
+  F(L.w, E.ps.w.x); F(L.w + 1, E.ps.w.y); F(L.w + 2, E.ps.w.z);
+#pragma unroll
+  for (int j = 0; j < NQ; j++) { F(L.q + j, E.ps.q[j]); F(L.qd + j, E.ps.qd[j]); }
+  F(L.goal, E.goal[0]); F(L.goal + 1, E.goal[1]); F(L.pot, E.pot); F(L.prog, E.prog);
+  F(L.goals, E.goals); F(L.egoals, E.egoals);
+#pragma unroll
+  for (int k = 0; k < 5; k++) F(L.dr + k, E.dr[k]);
+  F(L.xyprev, E.xyprev[0]); F(L.xyprev + 1, E.xyprev[1]);
+  si[(size_t)I_TIMESTEP * N + e] = E.timestep; si[(size_t)I_MASK * N + e] = E.mask; si[(size_t)I_RNG * N + e] = E.rng;
+}
+
+// SoloBase.get_current_state (solo.py:198-222): D values, compile-time indices
+template <typename T, int ROBOT>
+SD void current_state(const Env<T, Robot<ROBOT>::NQ>& E, int task, T (&cs)[DMAX]) {
+  constexpr int NQ = Robot<ROBOT>::NQ;
+  T r, p, y;
+  euler_zyx(E.ps.qx, E.ps.qy, E.ps.qz, E.ps.qw, r, p, y);
+  cs[0] = E.ps.pos.z;
+  cs[1] = (r - T(2) * floor(r * T(0.5))) * T(0.5);   // (euler % 2*pi)/(2*pi) == (euler % 2)/2, solo.py:206
+  cs[2] = (p - T(2) * floor(p * T(0.5))) * T(0.5);
+  cs[3] = (y - T(2) * floor(y * T(0.5))) * T(0.5);
+  cs[4] = E.ps.v.x; cs[5] = E.ps.v.y; cs[6] = E.ps.v.z;
+  cs[7] = E.ps.w.x; cs[8] = E.ps.w.y; cs[9] = E.ps.w.z;
+#pragma unroll
+  for (int j = 0; j < NQ; j++) { cs[10 + j] = E.ps.q[j] / T(10); cs[10 + NQ + j] = E.ps.qd[j] / T(100); }
+#pragma unroll
+  for (int f = 0; f < 4; f++) cs[10 + 2 * NQ + f] = ((E.mask >> (13 + 2 * f)) & 1) ? T(1) : T(0);
+  if (task == SOLORL_TASK_POINTGOAL) {
+    cs[14 + 2 * NQ] = E.ps.pos.x * T(0.5); cs[15 + 2 * NQ] = E.ps.pos.y * T(0.5);
+    cs[16 + 2 * NQ] = E.goal[0] * T(0.5); cs[17 + 2 * NQ] = E.goal[1] * T(0.5);
+  }
+}
+
+template <typename T, int NQ>
+SD void sample_goal(Env<T, NQ>& E, const EnvParams& P, long long gid) {   // solo.py:325-330
+  unsigned r[4];
+  philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)E.rng++, 1u, r);
+  T span = T(P.goal_radius - 1.0);
+  T x = T(1) + T((double)(r[0] >> 8) * (1.0 / 16777216.0)) * span;
+  T y = T(1) + T((double)(r[1] >> 8) * (1.0 / 16777216.0)) * span;
+  E.goal[0] = (r[2] & 1u) ? x : -x; E.goal[1] = (r[3] & 1u) ? y : -y;
+}
+
+// SoloBaseEnv.reset (baseEnv.py:70-82) in O(1): load the pre-simulated post-settle state.
+template <typename T, int ROBOT>
+SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L, size_t N, size_t e, const T* snf,
+                            const int* sni, int M, const EnvParams& P) {
+  constexpr int NQ = Robot<ROBOT>::NQ;
+  const long long gid = P.id0 + (long long)e;
+  int rng = E.rng;
+  T g0 = E.goal[0], g1 = E.goal[1];
+  Env<T, NQ> S;
+  // order of draws as the reference: goal (robot.reset), then the settle count (env.reset)
+  E.rng = rng;
+  if (P.task == SOLORL_TASK_POINTGOAL) { sample_goal(E, P, gid); g0 = E.goal[0]; g1 = E.goal[1]; }
+  rng = E.rng;
+  unsigned r[4];
+  philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)rng++, 2u, r);
+  const int k = (int)(r[0] % (unsigned)P.nsettle);
+  load_env(S, snf, sni, L, (size_t)M, (size_t)k);
+  E = S;
+  E.rng = rng; E.timestep = 0;
+  E.goal[0] = g0; E.goal[1] = g1; E.goals = T(0); E.egoals = T(0);
+#pragma unroll
+  for (int q = 0; q < 5; q++) E.dr[q] = T(0);
+  for (int p = 0; p < NPRIM; p++) sf[(size_t)(L.lam + p) * N + e] = snf[(size_t)(L.lam + p) * M + k];
+  for (int h = 0; h < L.H; h++)
+    for (int d = 0; d < L.D; d++) sf[(size_t)(L.hist + h * DMAX + d) * N + e] = snf[(size_t)(L.hist + h * DMAX + d) * M + k];
+  if (P.task == SOLORL_TASK_POINTGOAL) {
+    for (int h = 0; h < L.H; h++) {
+      sf[(size_t)(L.hist + h * DMAX + L.D - 2) * N + e] = g0 * T(0.5);
+      sf[(size_t)(L.hist + h * DMAX + L.D - 1) * N + e] = g1 * T(0.5);
+    }
+    T dx = E.ps.pos.x - g0, dy = E.ps.pos.y - g1, px = E.xyprev[0] - g0, py = E.xyprev[1] - g1;
+    E.pot = sqrt(dx * dx + dy * dy);
+    E.prog = -(E.pot - sqrt(px * px + py * py));
+  }
+}
+
+template <typename T, int ROBOT>
+SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& L, size_t N, size_t e, int task, float* obs) {
+  T cs[DMAX];
+  current_state<T, ROBOT>(E, task, cs);
+  const int O = L.D * (1 + L.H);
+  float* o = obs + e * (size_t)O;
+  // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older]
+#pragma unroll
+  for (int d = 0; d < DMAX; d++)
+    if (d < L.D) {
+      o[d] = (float)cs[d];
+      for (int h = 0; h < L.H; h++) o[(h + 1) * L.D + d] = (float)(cs[d] - sf[(size_t)(L.hist + h * DMAX + d) * N + e]);
+    }
+}
+
+// ---------------------------------------------------------------- the hot kernel
+template <typename T, int ROBOT, int EPB>
+__global__ void __launch_bounds__(EPB)
+step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
+            Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
+  using RB = Robot<ROBOT>;
+  constexpr int NQ = RB::NQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const size_t e = (size_t)blockIdx.x * EPB + lane;
+  if (e >= (size_t)N) return;
+  RowLds<T> lds; lds.carve(smem, EPB, lane);
+  Env<T, NQ> E;
+  load_env(E, sf, si, L, (size_t)N, e);
+
+  // ---- A3 apply_action
+  T tau[NQ], asq = T(0);
+#pragma unroll
+  for (int j = 0; j < NQ; j++) {
+    T a = mode == MODE_STEP ? (T)actions[e * NQ + j] : T(0);
+    asq += a * a;
+    T c = a < T(-1) ? T(-1) : (a > T(1) ? T(1) : a);
+    if (P.control == SOLORL_CONTROL_TORQUE) tau[j] = c * T(P.max_torque);
+    else {
+      T t = T(P.kp) * (c * pp.qlim - E.ps.q[j]) - T(P.kd) * E.ps.qd[j];
+      tau[j] = clampv(t, T(P.max_torque));
+    }
+    if (mode != MODE_STEP) tau[j] = T(0);
+  }
+
+  // ---- A4 simulator_step: history push (pre-step state), frame_skip sub-steps
+  if (L.H > 0) {
+    T cs[DMAX];
+    current_state<T, ROBOT>(E, P.task, cs);
+#pragma unroll
+    for (int d = 0; d < DMAX; d++)
+      if (d < L.D) {
+        if (L.H == 2) sf[(size_t)(L.hist + DMAX + d) * N + e] = sf[(size_t)(L.hist + d) * N + e];
+        sf[(size_t)(L.hist + d) * N + e] = cs[d];
+      }
+  }
+  E.xyprev[0] = E.ps.pos.x; E.xyprev[1] = E.ps.pos.y;
+#pragma unroll 1
+  for (int ss = 0; ss < P.frame_skip; ss++) {
+    T te[NQ];
+    const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
+#pragma unroll
+    for (int j = 0; j < NQ; j++) te[j] = tau[j] * sc;
+    E.mask = substep<T, ROBOT>(E.ps, te, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
+  }
+  if (P.task == SOLORL_TASK_POINTGOAL && mode == MODE_STEP) {
+    T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
+    T np = sqrt(dx * dx + dy * dy);
+    E.prog = -(np - E.pot); E.pot = np;
+    if (np < T(0.5)) { E.goals += T(1); sample_goal(E, P, P.id0 + (long long)e); }
+  }
+  if (mode == MODE_SETTLE) { store_env(E, sf, si, L, (size_t)N, e); return; }
+  E.timestep += 1;
+
+  // ---- A7 reward (baseEnv.py:91-157)
+  const T z = E.ps.pos.z;
+  T stand = z > T(0.2) ? T(0.5) : T(0), jp = T(0), balance = T(0), progress = T(0), torque = T(0);
+#pragma unroll
+  for (int j = 0; j < NQ; j++) jp += P.task == SOLORL_TASK_STAND ? fabs(E.ps.q[j]) : E.ps.q[j] * E.ps.q[j];
+  jp = T(-0.1) * jp / T(NQ);
+  if (P.task == SOLORL_TASK_WALK) {
+    if (z > T(0.2)) { T vx = E.ps.v.x; progress = T(2) * (vx > T(0) ? T(1) : (vx < T(0) ? T(-1) : T(0))) * vx * vx; }
+  } else if (P.task == SOLORL_TASK_POINTGOAL) {
+    T r, p, y; euler_zyx(E.ps.qx, E.ps.qy, E.ps.qz, E.ps.qw, r, p, y);
+    balance = T(-0.1) * (fabs(r) + fabs(p));
+    if (z > T(0.2)) progress = E.prog * T(1.0 / P.reward_dt);
+  }
+  if (P.control == SOLORL_CONTROL_TORQUE) torque = T(-0.01) * asq;
+  T reward = stand + jp + balance + progress + torque;
+  E.dr[0] += stand; E.dr[1] += jp; E.dr[2] += torque; E.dr[3] += balance; E.dr[4] += progress;
+
+  // ---- A8 termination (baseEnv.py:162-180) + NaN guard
+  int done = 0, to = 0, su = 0, nanr = 0;
+  {
+    T chk = E.ps.pos.x + E.ps.pos.y + E.ps.pos.z + E.ps.qw + E.ps.v.x + E.ps.v.y + E.ps.v.z + E.ps.w.x + E.ps.w.y + E.ps.w.z;
+#pragma unroll
+    for (int j = 0; j < NQ; j++) chk += E.ps.q[j] + E.ps.qd[j];
+    if (!(fabs(chk) < T(1e30))) { nanr = 1; done = 1; reward = T(0); }
+  }
+  if (!P.disable_termination && !nanr) {
+    if (E.timestep >= P.episode_length) { done = 1; to = 1; su = P.task != SOLORL_TASK_POINTGOAL; }
+    else if (z < T(0.05)) { done = 1; }
+    else if (P.task == SOLORL_TASK_POINTGOAL && E.goals > E.egoals) { E.egoals = E.goals; done = 1; su = 1; }
+  }
+  if (done && !nanr) {   // baseEnv.py:52-60
+    if (su) { if (P.task == SOLORL_TASK_POINTGOAL) reward = T(0.1) * T(P.episode_length - E.timestep); }
+    else if (!to) reward = T(-10);
+  }
+  out.rew[e] = (float)reward;
+  out.done[e] = (unsigned char)done;
+  if (out.timeout) out.timeout[e] = (unsigned char)to;
+  if (out.success) out.success[e] = (unsigned char)su;
+  if (out.nan_reset) out.nan_reset[e] = (unsigned char)nanr;
+  if (out.ep_len) out.ep_len[e] = E.timestep;
+  if (out.ep_rew) out.ep_rew[e] = (float)reward;
+  if (out.goals) out.goals[e] = (float)E.egoals;
+  if (out.dr0) out.dr0[e] = (float)E.dr[0];
+  if (out.dr1) out.dr1[e] = (float)E.dr[1];
+  if (out.dr2) out.dr2[e] = (float)E.dr[2];
+  if (out.dr3) out.dr3[e] = (float)E.dr[3];
+  if (out.dr4) out.dr4[e] = (float)E.dr[4];
+
+  // ---- auto-reset (agents/ppo/envs.py:39) and observation
+  if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, snf, sni, M, P);
+  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, P.task, out.obs);
+  store_env(E, sf, si, L, (size_t)N, e);
+}
+
+template <typename T, int ROBOT>
+__global__ void reset_kernel(T* sf, int* si, const T* snf, const int* sni, int M, Layout L, int N, EnvParams P, float* obs) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N) return;
+  Env<T, Robot<ROBOT>::NQ> E;
+  load_env(E, sf, si, L, (size_t)N, e);
+  reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, snf, sni, M, P);
+  if (obs) write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, P.task, obs);
+  store_env(E, sf, si, L, (size_t)N, e);
+  si[(size_t)I_NEEDRESET * N + e] = 0;
+}
+
+template <typename T, int ROBOT>
+__global__ void obs_kernel(const T* sf, const int* si, Layout L, int N, int task, float* obs) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N) return;
+  Env<T, Robot<ROBOT>::NQ> E;
+  load_env(E, sf, si, L, (size_t)N, e);
+  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, task, obs);
+}
+
+// initial pose of SoloBase.robot_specific_reset (solo.py:291-296) for every env of a buffer
+template <typename T>
+__global__ void init_pose_kernel(T* sf, int* si, Layout L, int N) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N) return;
+  for (int f = 0; f < L.NF; f++) sf[(size_t)f * N + e] = T(0);
+  sf[(size_t)(L.pos + 2) * N + e] = T(0.35);
+  sf[(size_t)(L.quat + 3) * N + e] = T(1);
+  for (int k = 0; k < NI; k++) si[(size_t)k * N + e] = 0;
+  si[(size_t)I_NEEDRESET * N + e] = 1;
+}
+
+template <typename T>
+__global__ void copy_env_kernel(const T* sf, const int* si, int N, int src, T* df, int* di, int M, int dst, int NF) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < NF) df[(size_t)f * M + dst] = sf[(size_t)f * N + src];
+  if (f < NI) di[(size_t)f * M + dst] = si[(size_t)f * N + src];
+}
+
+}  // namespace
+
+// ================================================================== host side
+struct solorl_env {
+  solorl_config cfg;
+  int N = 0, device = 0, n = 0, D = 0, O = 0, M = 0;
+  bool f64 = false, reset_called = false;
+  size_t tsize = 4;
+  Layout L;
+  void* sf = nullptr; int* si = nullptr; void* snf = nullptr; int* sni = nullptr;
+  uint64_t seed = 0; int64_t id0 = 0;
+  double goal_radius = 2.0;
+  size_t smem = 0;
+};
+
+namespace {
+
+EnvParams make_env_params(const solorl_env* h) {
+  EnvParams P;
+  const solorl_config& c = h->cfg;
+  P.task = c.task; P.control = c.control; P.frame_skip = c.frame_skip; P.episode_length = c.episode_length;
+  P.hold_torque = c.hold_torque; P.disable_termination = c.disable_termination;
+  P.settle_min = c.settle_min; P.nsettle = c.settle_max - c.settle_min + 1;
+  P.seed_lo = (unsigned)h->seed; P.seed_hi = (unsigned)(h->seed >> 32); P.id0 = h->id0;
+  P.kp = c.kp; P.kd = c.kd; P.max_torque = c.max_torque; P.reward_dt = c.reward_dt; P.goal_radius = h->goal_radius;
+  return P;
+}
+template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
+  PhysParams<T> p;
+  p.dt = (T)c.sim_dt; p.gravity = (T)c.gravity; p.erp = (T)c.erp; p.slop = (T)c.linear_slop; p.warm = (T)c.warmstart;
+  p.damping = (T)c.damping; p.vmax = (T)c.max_velocity; p.qlim = (T)c.joint_limit; p.inv_dt = (T)(1.0 / c.sim_dt);
+  p.iterations = c.solver_iterations;
+  return p;
+}
+
+template <typename T, int ROBOT, int EPB>
+int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
+  auto kern = step_kernel<T, ROBOT, EPB>;
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  int dev = h->device & 7;
+  if (!attr_set[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    attr_set[dev] = true;
+  }
+  dim3 grid((N + EPB - 1) / EPB), block(EPB);
+  hipLaunchKernelGGL(kern, grid, block, h->smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
+                     make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dispatch_step(solorl_env* h, void* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
+  const bool s12 = h->cfg.robot == SOLORL_ROBOT_SOLO12;
+  if (!h->f64) return s12 ? launch_step<float, 1, 64>(h, (float*)sf, si, N, actions, out, mode, st)
+                          : launch_step<float, 0, 64>(h, (float*)sf, si, N, actions, out, mode, st);
+  return s12 ? launch_step<double, 1, 32>(h, (double*)sf, si, N, actions, out, mode, st)
+             : launch_step<double, 0, 32>(h, (double*)sf, si, N, actions, out, mode, st);
+}
+
+template <typename T> int build_snapshots_t(solorl_env* h) {
+  // one scratch env simulated from the reset pose; its state after k = settle_min..settle_max
+  // zero-torque control steps is copied into snapshot slot k - settle_min.
+  T* tf = nullptr; int* ti = nullptr;
+  HIP_TRY(hipMalloc(&tf, sizeof(T) * h->L.NF)); HIP_TRY(hipMalloc(&ti, sizeof(int) * NI));
+  hipLaunchKernelGGL(init_pose_kernel<T>, dim3(1), dim3(64), 0, 0, tf, ti, h->L, 1);
+  Outputs none; memset(&none, 0, sizeof none);
+  for (int k = 1; k <= h->cfg.settle_max; k++) {
+    int rc = dispatch_step(h, tf, ti, 1, nullptr, none, MODE_SETTLE, 0);
+    if (rc) return rc;
+    if (k >= h->cfg.settle_min)
+      hipLaunchKernelGGL(copy_env_kernel<T>, dim3((h->L.NF + 63) / 64), dim3(64), 0, 0, (const T*)tf, (const int*)ti, 1, 0,
+                         (T*)h->snf, h->sni, h->M, k - h->cfg.settle_min, h->L.NF);
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipFree(tf)); HIP_TRY(hipFree(ti));
+  return 0;
+}
+
+int check_cfg(const solorl_config* c) {
+  if (!c) return fail(SOLORL_ERR_INVALID, "null config");
+  if (c->robot != SOLORL_ROBOT_SOLO8 && c->robot != SOLORL_ROBOT_SOLO12) return fail(SOLORL_ERR_INVALID, "robot must be SOLO8 or SOLO12");
+  if (c->task < 0 || c->task > 2) return fail(SOLORL_ERR_INVALID, "task must be stand/walk/pointgoal");
+  if (c->control != SOLORL_CONTROL_TORQUE && c->control != SOLORL_CONTROL_PD) return fail(SOLORL_ERR_INVALID, "control must be torque or pd");
+  if (c->frame_skip < 1 || c->frame_skip > 64) return fail(SOLORL_ERR_INVALID, "frame_skip out of range");
+  if (c->num_history_stack < 0 || c->num_history_stack > 2) return fail(SOLORL_ERR_INVALID, "num_history_stack must be 0..2");
+  if (c->episode_length < 1) return fail(SOLORL_ERR_INVALID, "episode_length must be >= 1");
+  if (c->settle_min < 0 || c->settle_max < c->settle_min || c->settle_max > 64) return fail(SOLORL_ERR_INVALID, "bad settle range");
+  if (c->settle_min < c->num_history_stack) return fail(SOLORL_ERR_INVALID, "settle_min must be >= num_history_stack");
+  if (c->solver_iterations < 1 || c->solver_iterations > 1000) return fail(SOLORL_ERR_INVALID, "solver_iterations out of range");
+  if (c->use_urdf_inertia) return fail(SOLORL_ERR_INVALID, "use_urdf_inertia=1 is not implemented by the HIP engine (box inertia, K2, only)");
+  if (!(c->sim_dt > 0) || !(c->goal_radius > 1.0)) return fail(SOLORL_ERR_INVALID, "sim_dt must be > 0 and goal_radius > 1");
+  if (c->precision != SOLORL_PRECISION_F32 && c->precision != SOLORL_PRECISION_F64) return fail(SOLORL_ERR_INVALID, "bad precision");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* solorl_last_error(void) { return g_err.c_str(); }
+const char* solorl_version(void) { return "solorl-hip 0.1 (gfx950)"; }
+
+int solorl_default_config(solorl_config* c, int robot, int task) {
+  if (!c) return fail(SOLORL_ERR_INVALID, "null config");
+  memset(c, 0, sizeof *c);
+  c->robot = robot; c->task = task; c->control = SOLORL_CONTROL_TORQUE;
+  c->frame_skip = 4; c->episode_length = 400; c->num_history_stack = 0;
+  c->solver_iterations = 50; c->settle_min = 5; c->settle_max = 11; c->precision = SOLORL_PRECISION_F32;
+  c->kp = 5.0; c->kd = 0.2; c->max_torque = 3.0; c->sim_dt = 1.0 / 240.0; c->reward_dt = 1.0 / 60.0; c->gravity = 9.81;
+  c->erp = 0.2; c->linear_slop = 1e-5; c->warmstart = 0.85; c->damping = 0.04; c->max_velocity = 100.0;
+  c->joint_limit = 10.0; c->goal_radius = 2.0;
+  return 0;
+}
+
+int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_t seed, int64_t env_id_offset, solorl_env** out) {
+  if (!out) return fail(SOLORL_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (num_envs < 1) return fail(SOLORL_ERR_INVALID, "num_envs must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SOLORL_ERR_NODEVICE, "no HIP device available (the engine has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(SOLORL_ERR_NODEVICE, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  solorl_env* h = new solorl_env();
+  h->cfg = *cfg; h->N = num_envs; h->device = device_id; h->seed = seed; h->id0 = env_id_offset;
+  h->n = cfg->robot == SOLORL_ROBOT_SOLO12 ? 12 : 8;
+  h->D = 14 + 2 * h->n + (cfg->task == SOLORL_TASK_POINTGOAL ? 4 : 0);
+  h->O = h->D * (1 + cfg->num_history_stack);
+  h->f64 = cfg->precision == SOLORL_PRECISION_F64; h->tsize = h->f64 ? 8 : 4;
+  h->L = make_layout(h->n, h->D, cfg->num_history_stack);
+  h->M = cfg->settle_max - cfg->settle_min + 1;
+  h->goal_radius = cfg->goal_radius;
+  h->smem = h->f64 ? RowLds<double>::bytes(32) : RowLds<float>::bytes(64);
+  auto cleanup = [&](int code) { solorl_destroy(h); return code; };
+  if (hipMalloc(&h->sf, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state"));
+  if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
+  if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
+  if (hipMalloc(&h->sni, sizeof(int) * NI * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
+  dim3 g((num_envs + 255) / 256), b(256);
+  if (h->f64) hipLaunchKernelGGL(init_pose_kernel<double>, g, b, 0, 0, (double*)h->sf, h->si, h->L, num_envs);
+  else hipLaunchKernelGGL(init_pose_kernel<float>, g, b, 0, 0, (float*)h->sf, h->si, h->L, num_envs);
+  rc = h->f64 ? build_snapshots_t<double>(h) : build_snapshots_t<float>(h);
+  if (rc) return cleanup(rc);
+  if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "device sync after create"));
+  *out = h;
+  return 0;
+}
+
+int solorl_destroy(solorl_env* h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->sf) hipFree(h->sf);
+  if (h->si) hipFree(h->si);
+  if (h->snf) hipFree(h->snf);
+  if (h->sni) hipFree(h->sni);
+  delete h;
+  return 0;
+}
+
+int solorl_dims(const solorl_env* h, int* obs_dim, int* act_dim, int* num_envs) {
+  if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
+  if (obs_dim) *obs_dim = h->O;
+  if (act_dim) *act_dim = h->n;
+  if (num_envs) *num_envs = h->N;
+  return 0;
+}
+
+int solorl_reset(solorl_env* h, float* obs_out, void* stream) {
+  if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
+  hipStream_t st = (hipStream_t)stream;
+  EnvParams P = make_env_params(h);
+  dim3 g((h->N + 255) / 256), b(256);
+  const bool s12 = h->cfg.robot == SOLORL_ROBOT_SOLO12;
+  if (h->f64) {
+    if (s12) hipLaunchKernelGGL((reset_kernel<double, 1>), g, b, 0, st, (double*)h->sf, h->si, (const double*)h->snf, (const int*)h->sni, h->M, h->L, h->N, P, obs_out);
+    else hipLaunchKernelGGL((reset_kernel<double, 0>), g, b, 0, st, (double*)h->sf, h->si, (const double*)h->snf, (const int*)h->sni, h->M, h->L, h->N, P, obs_out);
+  } else {
+    if (s12) hipLaunchKernelGGL((reset_kernel<float, 1>), g, b, 0, st, (float*)h->sf, h->si, (const float*)h->snf, (const int*)h->sni, h->M, h->L, h->N, P, obs_out);
+    else hipLaunchKernelGGL((reset_kernel<float, 0>), g, b, 0, st, (float*)h->sf, h->si, (const float*)h->snf, (const int*)h->sni, h->M, h->L, h->N, P, obs_out);
+  }
+  HIP_TRY(hipGetLastError());
+  h->reset_called = true;
+  return 0;
+}
+
+int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,
+                const solorl_info_soa* info, void* stream) {
+  if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
+  if (!h->reset_called) return fail(SOLORL_ERR_STATE, "env.reset() must be called before step");   // baseEnv.py:43
+  if (!actions || !obs_out || !reward_out || !done_out) return fail(SOLORL_ERR_INVALID, "null array argument");
+  Outputs o; memset(&o, 0, sizeof o);
+  o.obs = obs_out; o.rew = reward_out; o.done = done_out;
+  if (info) {
+    o.timeout = info->timeout; o.success = info->success; o.nan_reset = info->nan_reset; o.ep_len = info->episode_length;
+    o.ep_rew = info->episode_reward; o.goals = info->goals_reached; o.dr0 = info->dr_stand; o.dr1 = info->dr_joint_pose;
+    o.dr2 = info->dr_torque; o.dr3 = info->dr_balance; o.dr4 = info->dr_progress;
+  }
+  return dispatch_step(h, h->sf, h->si, h->N, actions, o, MODE_STEP, (hipStream_t)stream);
+}
+
+int solorl_get_observation(solorl_env* h, float* obs_out, void* stream) {
+  if (!h || !obs_out) return fail(SOLORL_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g((h->N + 255) / 256), b(256);
+  const bool s12 = h->cfg.robot == SOLORL_ROBOT_SOLO12;
+  if (h->f64) {
+    if (s12) hipLaunchKernelGGL((obs_kernel<double, 1>), g, b, 0, st, (const double*)h->sf, (const int*)h->si, h->L, h->N, h->cfg.task, obs_out);
+    else hipLaunchKernelGGL((obs_kernel<double, 0>), g, b, 0, st, (const double*)h->sf, (const int*)h->si, h->L, h->N, h->cfg.task, obs_out);
+  } else {
+    if (s12) hipLaunchKernelGGL((obs_kernel<float, 1>), g, b, 0, st, (const float*)h->sf, (const int*)h->si, h->L, h->N, h->cfg.task, obs_out);
+    else hipLaunchKernelGGL((obs_kernel<float, 0>), g, b, 0, st, (const float*)h->sf, (const int*)h->si, h->L, h->N, h->cfg.task, obs_out);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int solorl_increment_curriculum(solorl_env* h, double value) {
+  if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
+  if (h->cfg.task == SOLORL_TASK_POINTGOAL) h->goal_radius += value;   // solo.py:332-334
+  return 0;
+}
+
+int solorl_get_state(solorl_env* h, int i, solorl_env_state* out) {
+  if (!h || !out || i < 0 || i >= h->N) return fail(SOLORL_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<double> f(h->L.NF);
+  int iv[NI];
+  if (h->f64) {
+    HIP_TRY(hipMemcpy2D(f.data(), sizeof(double), (const char*)h->sf + sizeof(double) * (size_t)i, sizeof(double) * (size_t)h->N, sizeof(double), h->L.NF, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<float> ff(h->L.NF);
+    HIP_TRY(hipMemcpy2D(ff.data(), sizeof(float), (const char*)h->sf + sizeof(float) * (size_t)i, sizeof(float) * (size_t)h->N, sizeof(float), h->L.NF, hipMemcpyDeviceToHost));
+    for (int k = 0; k < h->L.NF; k++) f[k] = ff[k];
+  }
+  HIP_TRY(hipMemcpy2D(iv, sizeof(int), (const char*)h->si + sizeof(int) * (size_t)i, sizeof(int) * (size_t)h->N, sizeof(int), NI, hipMemcpyDeviceToHost));
+  const Layout& L = h->L;
+  memset(out, 0, sizeof *out);
+  for (int k = 0; k < 3; k++) { out->pos[k] = f[L.pos + k]; out->lin_vel[k] = f[L.v + k]; out->ang_vel[k] = f[L.w + k]; }
+  for (int k = 0; k < 4; k++) out->quat[k] = f[L.quat + k];
+  for (int j = 0; j < h->n; j++) { out->q[j] = f[L.q + j]; out->qd[j] = f[L.qd + j]; }
+  for (int p = 0; p < NPRIM; p++) out->lambda_prev[p] = f[L.lam + p];
+  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) out->hist[hh][d] = f[L.hist + hh * DMAX + d];
+  out->goal[0] = f[L.goal]; out->goal[1] = f[L.goal + 1]; out->potential = f[L.pot]; out->progress = f[L.prog];
+  out->goals_reached = f[L.goals]; out->env_goals_reached = f[L.egoals];
+  for (int k = 0; k < 5; k++) out->dr[k] = f[L.dr + k];
+  out->timestep = iv[I_TIMESTEP]; out->contact_mask = iv[I_MASK]; out->rng_counter = iv[I_RNG]; out->need_reset = iv[I_NEEDRESET];
+  return 0;
+}
+
+int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
+  if (!h || !in || i < 0 || i >= h->N) return fail(SOLORL_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const Layout& L = h->L;
+  std::vector<double> f(L.NF, 0.0);
+  for (int k = 0; k < 3; k++) { f[L.pos + k] = in->pos[k]; f[L.v + k] = in->lin_vel[k]; f[L.w + k] = in->ang_vel[k]; }
+  for (int k = 0; k < 4; k++) f[L.quat + k] = in->quat[k];
+  for (int j = 0; j < h->n; j++) { f[L.q + j] = in->q[j]; f[L.qd + j] = in->qd[j]; }
+  for (int p = 0; p < NPRIM; p++) f[L.lam + p] = in->lambda_prev[p];
+  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) f[L.hist + hh * DMAX + d] = in->hist[hh][d];
+  f[L.goal] = in->goal[0]; f[L.goal + 1] = in->goal[1]; f[L.pot] = in->potential; f[L.prog] = in->progress;
+  f[L.goals] = in->goals_reached; f[L.egoals] = in->env_goals_reached;
+  for (int k = 0; k < 5; k++) f[L.dr + k] = in->dr[k];
+  f[L.xyprev] = in->pos[0]; f[L.xyprev + 1] = in->pos[1];
+  int iv[NI]; iv[I_TIMESTEP] = in->timestep; iv[I_MASK] = in->contact_mask; iv[I_RNG] = in->rng_counter; iv[I_NEEDRESET] = in->need_reset;
+  if (h->f64) {
+    HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(double) * (size_t)i, sizeof(double) * (size_t)h->N, f.data(), sizeof(double), sizeof(double), L.NF, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> ff(L.NF);
+    for (int k = 0; k < L.NF; k++) ff[k] = (float)f[k];
+    HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(float) * (size_t)i, sizeof(float) * (size_t)h->N, ff.data(), sizeof(float), sizeof(float), L.NF, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemcpy2D((char*)h->si + sizeof(int) * (size_t)i, sizeof(int) * (size_t)h->N, iv, sizeof(int), sizeof(int), NI, hipMemcpyHostToDevice));
+  if (!in->need_reset) h->reset_called = true;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// spatial.hpp -- register-resident 3-D / 6-D spatial algebra for the gfx950 rollout kernels.
+//
+// One environment per lane: every object below lives in VGPRs of ONE lane, all indices are
+// compile-time so nothing is demoted to scratch (cdna_hip_programming.md 5.4 rule 20).
+// All spatial quantities of one env are expressed in ONE frame -- world-aligned axes, origin at
+// the base-link origin -- so the articulated-body recursion needs no frame transforms: child
+// inertias and bias forces are simply added into the parent's.
+#pragma once
+#ifdef SOLO_HOST_SHIM          // tests/host_harness.cpp: same source compiled by g++ for CPU debugging
+#include "host_shim.hpp"
+#else
+#include <hip/hip_runtime.h>
+#define SD __device__ __forceinline__
+#endif
+
+namespace solo {
+
+template <typename T> struct V3 { T x, y, z; };
+
+template <typename T> SD V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> SD V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> SD V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> SD V3<T> operator-(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <typename T> SD V3<T> operator*(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> SD V3<T> operator*(T s, V3<T> a) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> SD T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> SD V3<T> cross(V3<T> a, V3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T> SD V3<T> fma3(V3<T> a, T s, V3<T> acc) {  // acc + a*s
+  return {acc.x + a.x * s, acc.y + a.y * s, acc.z + a.z * s};
+}
+
+// rotation matrix stored by columns (c0,c1,c2 = images of the x,y,z axes)
+template <typename T> struct M3 { V3<T> c0, c1, c2; };
+template <typename T> SD V3<T> mul(const M3<T>& R, V3<T> v) { return R.c0 * v.x + R.c1 * v.y + R.c2 * v.z; }
+
+template <typename T> SD M3<T> quat_to_mat(T x, T y, T z, T w) {
+  M3<T> R;
+  R.c0 = {T(1) - T(2) * (y * y + z * z), T(2) * (x * y + z * w), T(2) * (x * z - y * w)};
+  R.c1 = {T(2) * (x * y - z * w), T(1) - T(2) * (x * x + z * z), T(2) * (y * z + x * w)};
+  R.c2 = {T(2) * (x * z + y * w), T(2) * (y * z - x * w), T(1) - T(2) * (x * x + y * y)};
+  return R;
+}
+// R * Rot(axis, q) for axis = x (AX=0) or y (AX=1): only two columns change
+template <int AX, typename T> SD M3<T> rot_axis(const M3<T>& R, T c, T s) {
+  M3<T> o;
+  if constexpr (AX == 0) { o.c0 = R.c0; o.c1 = R.c1 * c + R.c2 * s; o.c2 = R.c2 * c - R.c1 * s; }
+  else                   { o.c1 = R.c1; o.c0 = R.c0 * c - R.c2 * s; o.c2 = R.c2 * c + R.c0 * s; }
+  return o;
+}
+
+// spatial (Pluecker) vector: a = angular part (motion: omega, force: moment about the origin),
+// l = linear part (motion: velocity of the body point at the origin, force: force)
+template <typename T> struct SV { V3<T> a, l; };
+template <typename T> SD SV<T> operator+(SV<T> p, SV<T> q) { return {p.a + q.a, p.l + q.l}; }
+template <typename T> SD SV<T> operator-(SV<T> p, SV<T> q) { return {p.a - q.a, p.l - q.l}; }
+template <typename T> SD SV<T> operator*(SV<T> p, T s) { return {p.a * s, p.l * s}; }
+template <typename T> SD T dot(SV<T> p, SV<T> q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+template <typename T> SD SV<T> fma6(SV<T> p, T s, SV<T> acc) { return {fma3(p.a, s, acc.a), fma3(p.l, s, acc.l)}; }
+template <typename T> SD SV<T> zero6() { return {{T(0), T(0), T(0)}, {T(0), T(0), T(0)}}; }
+
+template <typename T> struct Sym3 { T xx, xy, xz, yy, yz, zz; };
+template <typename T> SD V3<T> mul(const Sym3<T>& S, V3<T> v) {
+  return {S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z,
+          S.xz * v.x + S.yz * v.y + S.zz * v.z};
+}
+template <typename T> SD void add(Sym3<T>& a, const Sym3<T>& b) {
+  a.xx += b.xx; a.xy += b.xy; a.xz += b.xz; a.yy += b.yy; a.yz += b.yz; a.zz += b.zz;
+}
+template <typename T> SD void rank1_sub(Sym3<T>& a, V3<T> u, V3<T> us) {  // a -= u * us^T (us = u*s)
+  a.xx -= u.x * us.x; a.xy -= u.x * us.y; a.xz -= u.x * us.z;
+  a.yy -= u.y * us.y; a.yz -= u.y * us.z; a.zz -= u.z * us.z;
+}
+
+// 6x6 symmetric (articulated-body) inertia  [[A, B], [B^T, C]]; B rows = angular index
+template <typename T> struct ABI { Sym3<T> A; V3<T> B0, B1, B2; Sym3<T> C; };
+
+template <typename T> SD SV<T> mul(const ABI<T>& I, SV<T> s) {
+  SV<T> r;
+  r.a = mul(I.A, s.a) + mk(dot(I.B0, s.l), dot(I.B1, s.l), dot(I.B2, s.l));
+  r.l = I.B0 * s.a.x + I.B1 * s.a.y + I.B2 * s.a.z + mul(I.C, s.l);
+  return r;
+}
+template <typename T> SD void add(ABI<T>& a, const ABI<T>& b) {
+  add(a.A, b.A); a.B0 = a.B0 + b.B0; a.B1 = a.B1 + b.B1; a.B2 = a.B2 + b.B2; add(a.C, b.C);
+}
+// I -= U (U*s)^T
+template <typename T> SD void rank1_sub(ABI<T>& I, SV<T> U, T s) {
+  SV<T> Us = U * s;
+  rank1_sub(I.A, U.a, Us.a);
+  I.B0 = I.B0 - Us.l * U.a.x; I.B1 = I.B1 - Us.l * U.a.y; I.B2 = I.B2 - Us.l * U.a.z;
+  rank1_sub(I.C, U.l, Us.l);
+}
+
+// rigid-body inertia about the common origin: mass m, first moment h = m*c, rotational inertia
+// Ibar about the origin.  As a 6x6: A = Ibar, B = skew(h), C = m*1.
+template <typename T> struct RBI { T m; V3<T> h; Sym3<T> I; };
+template <typename T> SD SV<T> mul(const RBI<T>& I, SV<T> s) {
+  return {mul(I.I, s.a) + cross(I.h, s.l), s.l * I.m - cross(I.h, s.a)};
+}
+template <typename T> SD void add(RBI<T>& a, const RBI<T>& b) { a.m += b.m; a.h = a.h + b.h; add(a.I, b.I); }
+template <typename T> SD ABI<T> to_abi(const RBI<T>& r) {
+  ABI<T> o;
+  o.A = r.I;
+  o.B0 = {T(0), -r.h.z, r.h.y}; o.B1 = {r.h.z, T(0), -r.h.x}; o.B2 = {-r.h.y, r.h.x, T(0)};
+  o.C = {r.m, T(0), T(0), r.m, T(0), r.m};
+  return o;
+}
+template <typename T> SD void add(ABI<T>& a, const RBI<T>& r) {
+  add(a.A, r.I);
+  a.B0.y -= r.h.z; a.B0.z += r.h.y; a.B1.x += r.h.z; a.B1.z -= r.h.x; a.B2.x -= r.h.y; a.B2.y += r.h.x;
+  a.C.xx += r.m; a.C.yy += r.m; a.C.zz += r.m;
+}
+
+// spatial motion cross product  v x m
+template <typename T> SD SV<T> crm(SV<T> v, SV<T> m) { return {cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)}; }
+
+// dense symmetric 6x6 with compile-time indexing (base inverse inertia)
+template <typename T> struct Sym6 { T m[6][6]; };
+template <typename T> SD SV<T> mul(const Sym6<T>& L, SV<T> f) {
+  T v[6] = {f.a.x, f.a.y, f.a.z, f.l.x, f.l.y, f.l.z}, r[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    T acc = T(0);
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc += L.m[i][j] * v[j];
+    r[i] = acc;
+  }
+  return {{r[0], r[1], r[2]}, {r[3], r[4], r[5]}};
+}
+
+// inverse of a symmetric positive definite 6x6 given as ABI (Cholesky, then L^-T L^-1)
+template <typename T> SD Sym6<T> spd_inverse(const ABI<T>& I) {
+  T a[6][6];
+  a[0][0] = I.A.xx; a[1][0] = I.A.xy; a[2][0] = I.A.xz; a[1][1] = I.A.yy; a[2][1] = I.A.yz; a[2][2] = I.A.zz;
+  a[3][0] = I.B0.x; a[4][0] = I.B0.y; a[5][0] = I.B0.z;
+  a[3][1] = I.B1.x; a[4][1] = I.B1.y; a[5][1] = I.B1.z;
+  a[3][2] = I.B2.x; a[4][2] = I.B2.y; a[5][2] = I.B2.z;
+  a[3][3] = I.C.xx; a[4][3] = I.C.xy; a[5][3] = I.C.xz; a[4][4] = I.C.yy; a[5][4] = I.C.yz; a[5][5] = I.C.zz;
+  T Lm[6][6], dinv[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    T d = a[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k];
+    T rs = T(1) / sqrt(d);
+    dinv[j] = rs; Lm[j][j] = d * rs;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      T v = a[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= Lm[i][k] * Lm[j][k];
+      Lm[i][j] = v * rs;
+    }
+  }
+  // X = L^-1 (lower triangular)
+  T X[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    X[j][j] = dinv[j];
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      T v = T(0);
+#pragma unroll
+      for (int k = j; k < i; k++) v -= Lm[i][k] * X[k][j];
+      X[i][j] = v * dinv[i];
+    }
+  }
+  Sym6<T> R;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      T v = T(0);
+#pragma unroll
+      for (int k = i; k < 6; k++) v += X[k][i] * X[k][j];
+      R.m[i][j] = v; R.m[j][i] = v;
+    }
+  return R;
+}
+
+}  // namespace solo

@@ -1,0 +1,195 @@
+"""Gym-style vec-env surface over the HIP engine -- the drop-in for the reference's
+``make_vec_envs`` -> ``PyTorchEnvWrapper(VecNormalize(VecEnvWrapper(...)))`` stack
+(agents/ppo/envs.py:14-30, :183-222).  Same attribute names, argument meaning and error behaviour:
+
+  reset() -> Tensor[N, O] f32                                  (envs.py:198-200)
+  step(actions Tensor[N, A]) -> (obs[N,O], reward[N,1], done[N] f32, infos)   (envs.py:189-196)
+  get_observation(), increment_curriculum(), close(), observation_space, action_space, nenvs
+
+torch is plumbing only: it owns the device buffers and the stream; all arithmetic happens in
+``libsolorl_hip.so`` on the caller's current HIP stream (no host synchronisation in step()).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from .config import SoloConfig, EnvState, InfoSoA, config_from_dict, TASK_POINTGOAL
+
+
+class Box:
+    """Stand-in for gym.spaces.Box: the policy dispatches on the class NAME
+    (agents/ppo/policy.py:22-31) and reads .shape / .high / .low."""
+
+    def __init__(self, low, high):
+        self.low = np.asarray(low, dtype=np.float32)
+        self.high = np.asarray(high, dtype=np.float32)
+        self.shape = self.low.shape
+        self.dtype = np.float32
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(np.float32)
+
+    def __repr__(self):
+        return "Box%s" % (self.shape,)
+
+
+_INFO_KEYS = ("timeout", "success", "nan_reset", "episode_length", "episode_reward", "goals_reached",
+              "dr_stand", "dr_joint_pose", "dr_torque", "dr_balance", "dr_progress")
+_DR_NAMES = {"dr_stand": "dr/stand_rew", "dr_joint_pose": "dr/joint_pose_rew", "dr_torque": "dr/torque_rew",
+             "dr_balance": "dr/roll_pitch_balance_rew", "dr_progress": "dr/progress_rew"}
+
+
+class LazyInfos:
+    """Sequence of per-env info dicts (reference: tuple of N dicts, envs.py:94-95) backed by SoA
+    device tensors; dicts are only materialised for the envs a caller actually indexes."""
+
+    def __init__(self, tensors, done):
+        self._t = tensors
+        self._done = done
+        self._host = None
+
+    def _fetch(self):
+        if self._host is None:
+            self._host = {k: v.cpu().numpy() for k, v in self._t.items()}
+        return self._host
+
+    def __len__(self):
+        return self._done.shape[0]
+
+    def __getitem__(self, i):
+        h = self._fetch()
+        d = {"episode_length": int(h["episode_length"][i]), "episode_reward": float(h["episode_reward"][i]),
+             "goals_reached": float(h["goals_reached"][i]),
+             # keys PPO reads at done but SoloBaseEnv never sets (SURVEY 8b [BUG]) -> 0.0
+             "max_velocity": 0.0, "min_force": 0.0, "max_force": 0.0, "nan_reset": bool(h["nan_reset"][i])}
+        for k, name in _DR_NAMES.items():
+            d[name] = float(h[k][i])
+        if h["done"][i]:
+            d["timeout"] = bool(h["timeout"][i])
+            d["success"] = bool(h["success"][i])
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def tensors(self):
+        """SoA device view: dict of [N] tensors (fast path for on-device episode statistics)."""
+        return self._t
+
+
+class SoloVecEnv:
+    """Batched SoloBaseEnv on one MI355X.  ``config`` is a reference-style dict (configs/*.yaml)
+    or a ``SoloConfig``."""
+
+    def __init__(self, config, num_envs, device=None, seed=1, env_id_offset=0, **overrides):
+        self.cfg = config.copy() if isinstance(config, SoloConfig) else config_from_dict(config, **overrides)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        device = torch.device(device) if device is not None else None
+        if device is None or device.type != "cuda":
+            raise _native.SoloRLError("SoloVecEnv needs a HIP device (got %r); the engine has no CPU fallback" % (device,))
+        self.device = device
+        self.L = _native.lib()
+        self.nenvs = int(num_envs)
+        h = C.c_void_p()
+        _native.check(self.L.solorl_create(C.byref(self.cfg), self.nenvs, device.index or 0, int(seed),
+                                           int(env_id_offset), C.byref(h)))
+        self._h = h
+        o, a, n = C.c_int(), C.c_int(), C.c_int()
+        _native.check(self.L.solorl_dims(self._h, C.byref(o), C.byref(a), C.byref(n)))
+        self.obs_dim, self.act_dim = o.value, a.value
+        self.observation_space = Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))  # baseEnv.py:27-28
+        self.action_space = Box(-np.ones(self.act_dim), np.ones(self.act_dim))                          # baseEnv.py:23-25
+        N = self.nenvs
+        kw = dict(device=device)
+        self._obs = torch.empty((N, self.obs_dim), dtype=torch.float32, **kw)
+        self._rew = torch.empty((N,), dtype=torch.float32, **kw)
+        self._done = torch.empty((N,), dtype=torch.uint8, **kw)
+        self._info = {k: torch.zeros((N,), dtype=(torch.uint8 if k in ("timeout", "success", "nan_reset") else
+                                                   torch.int32 if k == "episode_length" else torch.float32), **kw)
+                      for k in _INFO_KEYS}
+        self._info_c = InfoSoA(**{k: self._info[k].data_ptr() for k in _INFO_KEYS})
+        self.ob_rms = None          # VecNormalize(ob=False): agents/ppo/envs.py:26, read at train.py:126
+        self.closed = False
+
+    # reference call path: PyTorchEnvWrapper.envs (VecNormalize) .venv ...
+    @property
+    def envs(self):
+        return self
+
+    @property
+    def venv(self):
+        return self
+
+    def __len__(self):
+        return self.nenvs
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        with torch.cuda.device(self.device):
+            _native.check(self.L.solorl_reset(self._h, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        return self._obs.clone()
+
+    def step(self, actions):
+        if actions.shape != (self.nenvs, self.act_dim):
+            raise AssertionError("actions must be [%d, %d]" % (self.nenvs, self.act_dim))   # solo.py:226
+        a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _native.check(self.L.solorl_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                                             C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                             C.byref(self._info_c), self._stream()))
+        t = {k: v.clone() for k, v in self._info.items()}
+        t["done"] = self._done.clone()
+        return self._obs.clone(), self._rew.clone().unsqueeze(-1), t["done"].float(), LazyInfos(t, t["done"])
+
+    def step_inplace(self, actions):
+        """Zero-copy variant for rollout loops: returns views of the engine-owned output buffers
+        (overwritten by the next step)."""
+        with torch.cuda.device(self.device):
+            _native.check(self.L.solorl_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                                             C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                             C.byref(self._info_c), self._stream()))
+        return self._obs, self._rew, self._done, self._info
+
+    def get_observation(self):
+        with torch.cuda.device(self.device):
+            _native.check(self.L.solorl_get_observation(self._h, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        return self._obs.clone()
+
+    def increment_curriculum(self, value=1.0):
+        _native.check(self.L.solorl_increment_curriculum(self._h, float(value)))
+
+    def get_state(self, i=0):
+        s = EnvState()
+        _native.check(self.L.solorl_get_state(self._h, int(i), C.byref(s)))
+        return s
+
+    def set_state(self, i, s):
+        _native.check(self.L.solorl_set_state(self._h, int(i), C.byref(s)))
+
+    def close(self):
+        if not self.closed and getattr(self, "_h", None):
+            self.L.solorl_destroy(self._h)
+            self._h = None
+            self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_vec_envs(config, num_envs, env_constructor=None, gamma=0.99, device=None, training=True, seed=1,
+                  env_id_offset=0):
+    """Signature of agents/ppo/envs.py:14.  ``env_constructor`` (the per-process gym env class of the
+    reference) and ``gamma`` (VecNormalize's unused return accumulator, ob=False, ret=False) are
+    accepted for call-site compatibility and ignored."""
+    return SoloVecEnv(config, num_envs, device=device, seed=seed, env_id_offset=env_id_offset)
