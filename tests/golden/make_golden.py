@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Regenerates the fixtures under tests/golden/ (run in the build container only).
+
+  pd_golden.json        inputs/outputs of the reference's own controllers/PD.py::PD, obtained by
+                        importing that module BY FILE PATH from /root/reference (it is pure numpy).
+                        Only the vectors are committed, never reference source.
+  stand_pd_start.json   a settled crouched Solo12 state (fp64 oracle, 400 control steps of PD
+                        hold) = the common start of the 1000-step trajectory-parity run.
+  stand_pd_traj.npz     oracle joint angles of that run every 50 steps (actions: crouch +
+                        0.005*sin(2*pi*t/60 + j*pi/6), SURVEY.md 8d parity-run shape).
+"""
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+
+def make_pd():
+    spec = importlib.util.spec_from_file_location("ref_pd", "/root/reference/controllers/PD.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(7)
+    cases = [dict(q_ref=[1, -1, .5], q=[0, 0, 0], q_dot=[0, 1, 100], Kp=5, Kd=.2, limit=3)]
+    for _ in range(16):
+        n = 12
+        cases.append(dict(q_ref=(rng.uniform(-10, 10, n)).tolist(), q=rng.uniform(-10, 10, n).tolist(),
+                          q_dot=rng.uniform(-100, 100, n).tolist(), Kp=float(rng.uniform(0.5, 8)),
+                          Kd=float(rng.uniform(0.01, 0.5)), limit=3.0))
+    for c in cases:
+        c["tau"] = np.asarray(m.PD(np.array(c["q_ref"], float), np.array(c["q"], float), np.array(c["q_dot"], float),
+                                   c["Kp"], c["Kd"], c["limit"])).tolist()
+    json.dump(cases, open(os.path.join(HERE, "pd_golden.json"), "w"), indent=0)
+
+
+def stand_cfg():
+    from solorl_amd.config import default_config, ROBOT_SOLO12, TASK_STAND, CONTROL_PD
+    c = default_config(ROBOT_SOLO12, TASK_STAND)
+    c.num_history_stack = 1; c.settle_min = c.settle_max = 8; c.disable_termination = 1
+    c.control = CONTROL_PD; c.kp = 5.0; c.kd = 0.08; c.hold_torque = 1
+    return c
+
+
+CROUCH = np.array([0.0, 0.8, -1.6] * 4) / 10.0
+
+
+def stand_action(t, n=12):
+    return CROUCH + 0.005 * np.sin(2 * np.pi * t / 60 + np.arange(n) * np.pi / 6)
+
+
+def state_to_dict(s):
+    d = {}
+    for name, ctype in s._fields_:
+        v = getattr(s, name)
+        if hasattr(v, "__len__"):
+            v = [list(x) if hasattr(x, "__len__") else x for x in v]
+        d[name] = v
+    return d
+
+
+def state_from_dict(d):
+    from solorl_amd.config import EnvState
+    s = EnvState()
+    for name, _ in s._fields_:
+        v = d[name]
+        if isinstance(v, list):
+            tgt = getattr(s, name)
+            for i, x in enumerate(v):
+                if isinstance(x, list):
+                    for j, y in enumerate(x):
+                        tgt[i][j] = y
+                else:
+                    tgt[i] = x
+        else:
+            setattr(s, name, v)
+    return s
+
+
+def make_stand():
+    from oracle.oracle_py import Oracle
+    c = stand_cfg()
+    o = Oracle(c, 1, seed=1)
+    o.reset()
+    for t in range(400):
+        o.step(CROUCH[None])
+    s = o.get_state(0)
+    json.dump(state_to_dict(s), open(os.path.join(HERE, "stand_pd_start.json"), "w"))
+    qs, zs, ts = [], [], []
+    for t in range(1000):
+        o.step(stand_action(t)[None])
+        if (t + 1) % 50 == 0:
+            st = o.get_state(0)
+            qs.append(np.array(st.q)); zs.append(st.pos[2]); ts.append(t + 1)
+    np.savez(os.path.join(HERE, "stand_pd_traj.npz"), q=np.array(qs), z=np.array(zs), t=np.array(ts))
+
+
+if __name__ == "__main__":
+    make_pd()
+    make_stand()
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,83 @@
+"""The C-ABI library: loads, exports every symbol include/solorl.h declares, agrees with the Python
+mirror of the config, and fails loudly (no CPU fallback) without a GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from solorl_amd import _native, build
+from solorl_amd.config import (SoloConfig, EnvState, default_config, config_from_dict, load_yaml, ROBOT_SOLO8,
+                               ROBOT_SOLO12, TASK_WALK, TASK_POINTGOAL, TASK_STAND, CONTROL_PD)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _native.lib()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "solorl.h")).read()
+    declared = set(re.findall(r"\b(solorl_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_native.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s)
+    assert b"gfx950" in lib.solorl_version()
+
+
+def test_default_config_matches_python_mirror(lib):
+    for robot in (ROBOT_SOLO8, ROBOT_SOLO12):
+        for task in (TASK_STAND, TASK_WALK, TASK_POINTGOAL):
+            c = SoloConfig()
+            assert lib.solorl_default_config(C.byref(c), robot, task) == 0
+            assert bytes(c) == bytes(default_config(robot, task))
+    assert C.sizeof(SoloConfig) == 14 * 4 + 13 * 8
+    assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 20 + 2 * 42 + 2 + 4 + 5) + 4 * 4
+
+
+def test_error_convention(lib):
+    import torch
+    h = C.c_void_p()
+    c = default_config(ROBOT_SOLO12, TASK_WALK)
+    bad = c.copy(); bad.frame_skip = 0
+    assert lib.solorl_create(C.byref(bad), 4, 0, 1, 0, C.byref(h)) == -1
+    assert b"frame_skip" in lib.solorl_last_error()
+    bad = c.copy(); bad.use_urdf_inertia = 1
+    assert lib.solorl_create(C.byref(bad), 4, 0, 1, 0, C.byref(h)) == -1
+    assert lib.solorl_dims(None, None, None, None) == -1
+    if not torch.cuda.is_available():
+        # product path must fail loudly without a GPU: no CPU fallback, no oracle routing
+        assert lib.solorl_create(C.byref(c), 4, 0, 1, 0, C.byref(h)) == -2
+        assert b"no CPU fallback" in lib.solorl_last_error()
+        from solorl_amd.vec_env import SoloVecEnv
+        with pytest.raises(_native.SoloRLError):
+            SoloVecEnv(c, 4)
+
+
+def test_product_never_imports_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "solorl_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"#include\s*[\"<][^\">]*oracle", r"liboracle", r"oracle_py",
+                            r"(dlopen|CDLL)\([^)]*oracle"):
+                    assert not re.search(pat, txt, re.M), (f, pat)
+
+
+def test_reference_yaml_configs_load():
+    for name, robot, task, obs in [("basic.yaml", ROBOT_SOLO8, TASK_WALK, 60), ("basic12.yaml", ROBOT_SOLO12, TASK_POINTGOAL, 84)]:
+        d = load_yaml(os.path.join(ROOT, "configs", name))
+        c = config_from_dict(d)
+        assert (c.robot, c.task, c.frame_skip, c.episode_length, c.num_history_stack) == (robot, task, 4, 400, 1)
+        assert c.obs_dim == obs
+    c = config_from_dict(load_yaml(os.path.join(ROOT, "configs", "basic_pd.yaml")), episode_length=400)
+    assert c.control == CONTROL_PD and (c.kp, c.kd) == (5.0, 0.2)
+    c = config_from_dict(load_yaml(os.path.join(ROOT, "configs", "basic12.yaml")), task="walk")
+    assert c.task == TASK_WALK and c.obs_dim == 76
+    with pytest.raises(NotImplementedError):
+        config_from_dict(dict(episode_length=10, control="vpd"))
+    with pytest.raises(ValueError):
+        config_from_dict(dict(episode_length=10, task="fly"))

@@ -1,0 +1,98 @@
+"""The HIP engine's physics source (solorl_amd/csrc/{spatial,dynamics}.hpp) compiled by g++ for ONE
+lane (tests/host/) and checked against the fp64 oracle.  The two are different formulations
+(articulated-body recursion + base-space PGS  vs  dense mass matrix + Cholesky + generalized PGS),
+so agreement to rounding is the "ABA vs CRBA+Cholesky cross-check" of SURVEY.md section 7.
+This is a TEST build of the kernel source; nothing in solorl_amd/ can call it."""
+import numpy as np
+import pytest
+
+from solorl_amd.config import default_config, ROBOT_SOLO8, ROBOT_SOLO12, TASK_WALK
+from oracle.oracle_py import Oracle
+from tests.host import harness_py
+from tests.util import clone, state_vec, load_state
+from tests.golden.make_golden import stand_cfg, stand_action
+
+
+@pytest.mark.parametrize("robot,n", [(ROBOT_SOLO8, 8), (ROBOT_SOLO12, 12)])
+def test_free_flight_matches_dense_dynamics(robot, n):
+    c = default_config(robot, TASK_WALK)
+    rng = np.random.default_rng(0)
+    for trial in range(5):
+        o = Oracle(c, 1)
+        s = o.get_state(0); s.pos[2] = 5.0
+        for j in range(n):
+            s.q[j] = rng.uniform(-2, 2); s.qd[j] = rng.uniform(-5, 5); s.tau[j] = rng.uniform(-3, 3)
+        s.ang_vel[:] = list(rng.uniform(-2, 2, 3)); s.lin_vel[:] = list(rng.uniform(-1, 1, 3))
+        q = rng.normal(size=4); q /= np.linalg.norm(q); s.quat[:] = list(q)
+        o.set_state(0, s); h = clone(s)
+        o.substep(0); harness_py.substep(h, c, False)
+        assert np.abs(state_vec(o.get_state(0), n) - state_vec(h, n)).max() < 1e-11
+
+
+@pytest.mark.parametrize("robot,n", [(ROBOT_SOLO8, 8), (ROBOT_SOLO12, 12)])
+def test_contact_substeps_resynced(robot, n):
+    """Drop, land and thrash under random torques; every sub-step starts from the oracle's state.
+    The contact sets must be identical.  Errors are judged statistically: Bullet-style PGS with
+    mu = 1 box friction is a non-convergent fixed-point iteration in some multi-contact states
+    (DESIGN.md "Solver sensitivity"; frictionless it converges to 1e-16), where 50 iterations
+    amplify rounding by many orders of magnitude in BOTH implementations."""
+    c = default_config(robot, TASK_WALK)
+    rng = np.random.default_rng(1)
+    o = Oracle(c, 1)
+    e64, e32 = [], []
+    saw_contacts = 0
+    for k in range(400):
+        so = o.get_state(0)
+        if k % 4 == 0:
+            tau = rng.uniform(-1.0, 1.0, size=n)
+        for j in range(n):
+            so.tau[j] = tau[j] if k % 4 == 0 else 0.0
+        o.set_state(0, so)
+        h64, h32 = clone(so), clone(so)
+        o.substep(0)
+        harness_py.substep(h64, c, False); harness_py.substep(h32, c, True)
+        a = o.get_state(0)
+        assert a.contact_mask == h64.contact_mask
+        saw_contacts += bin(a.contact_mask).count("1") > 0
+        e64.append(np.abs(state_vec(a, n) - state_vec(h64, n)).max())
+        e32.append(np.abs(state_vec(a, n) - state_vec(h32, n)).max())
+    e64, e32 = np.array(e64), np.array(e32)
+    assert saw_contacts > 100
+    assert np.median(e64) < 1e-11 and np.percentile(e64, 90) < 1e-8 and e64.max() < 1e-3
+    assert np.median(e32) < 2e-4 and np.percentile(e32, 90) < 2e-2
+
+
+def test_joint_limit_row():
+    c = default_config(ROBOT_SOLO12, TASK_WALK)
+    for jj, qv, qdv in [(2, 9.9, 30), (0, 9.9, 30), (1, -9.95, -40), (2, 10.1, 5)]:
+        o = Oracle(c, 1)
+        s = o.get_state(0); s.pos[2] = 5.0; s.q[jj] = qv; s.qd[jj] = qdv
+        o.set_state(0, s); h = clone(s)
+        o.substep(0); harness_py.substep(h, c, False)
+        assert np.abs(state_vec(o.get_state(0), 12) - state_vec(h, 12)).max() < 1e-10
+
+
+def test_standing_trajectory_fp32_within_1e3_rad():
+    """The 1000-step trajectory-parity run (tests/golden: settled crouch start, PD hold, gentle
+    sinusoidal references) through the kernel math in fp32 on the CPU: joint angles stay within the
+    north-star tolerance 1e-3 rad of the fp64 oracle fixture."""
+    c = stand_cfg()
+    s = load_state("stand_pd_start.json")
+    gold = np.load(__import__("os").path.join(__import__("tests.util").util.GOLDEN, "stand_pd_traj.npz"))
+    h = clone(s)
+    worst = 0.0
+    for t in range(1000):
+        a = stand_action(t)
+        for ss in range(c.frame_skip):
+            for j in range(12):   # PD with hold_torque: recomputed once per control step from the pre-step state
+                if ss == 0:
+                    qref = np.clip(a[j], -1, 1) * 10
+                    h.tau[j] = float(np.clip(c.kp * (qref - h.q[j]) - c.kd * h.qd[j], -3, 3))
+            tau = [h.tau[j] for j in range(12)]
+            harness_py.substep(h, c, True)
+            for j in range(12):
+                h.tau[j] = tau[j]
+        if (t + 1) % 50 == 0:
+            k = (t + 1) // 50 - 1
+            worst = max(worst, np.abs(np.array(h.q) - gold["q"][k]).max())
+    assert worst < 1e-3, worst

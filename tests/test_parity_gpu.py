@@ -1,0 +1,214 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI (ctypes -> libsolorl_hip.so),
+against the fp64 oracle on the same seeded inputs, against the committed golden fixtures, and --
+at BASELINE.json's full size -- through size-independent properties.
+
+Tolerances (north_star: joint angles within 1e-3 rad):
+  * per control step from identical states (fp32 vs fp64): median joint error < 1e-4 rad, contact
+    sets equal, reward/obs within 1e-3 for the median env;
+  * 1000-step standing trajectory (golden fixture): max |dq| < 1e-3 rad;
+  * violent / frictionally jammed states are chaotic in BOTH implementations (DESIGN.md "Solver
+    sensitivity") and are judged statistically, never bit-for-bit.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from solorl_amd.config import (default_config, ROBOT_SOLO8, ROBOT_SOLO12, TASK_STAND, TASK_WALK, TASK_POINTGOAL,
+                               CONTROL_PD, CONTROL_TORQUE)
+from tests.util import GOLDEN, load_state
+from tests.golden.make_golden import stand_cfg, stand_action
+
+pytestmark = pytest.mark.gpu
+
+
+def make(cfg, N, seed=1, off=0):
+    from solorl_amd.vec_env import SoloVecEnv
+    from oracle.oracle_py import Oracle
+    return SoloVecEnv(cfg, N, device="cuda:0", seed=seed, env_id_offset=off), Oracle(cfg, N, seed=seed, env_id_offset=off)
+
+
+def cfg_for(robot, task, control=CONTROL_TORQUE, **kw):
+    c = default_config(robot, task); c.num_history_stack = 1; c.control = control
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_engine_library_is_loaded(gpu_device):
+    from solorl_amd import _native
+    assert os.path.exists(_native.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    _native.lib()
+    assert "libsolorl_hip.so" in open("/proc/self/maps").read() or "libsolorl_hip.so" in maps
+
+
+@pytest.mark.parametrize("robot,task", [(ROBOT_SOLO8, TASK_STAND), (ROBOT_SOLO12, TASK_WALK), (ROBOT_SOLO12, TASK_POINTGOAL)])
+def test_reset_matches_oracle(gpu_device, robot, task):
+    """reset = snapshot[K] on the GPU vs K live settle steps in the oracle; K and goals from Philox."""
+    c = cfg_for(robot, task)
+    env, orc = make(c, 256, seed=7)
+    og = env.reset().cpu().numpy().astype(np.float64); oo = orc.reset()
+    assert og.shape == oo.shape == (256, c.obs_dim)
+    assert np.abs(og - oo).max() < 2e-3
+    for i in (0, 17, 255):
+        sg, so = env.get_state(i), orc.get_state(i)
+        assert sg.rng_counter == so.rng_counter and sg.timestep == 0 and sg.contact_mask == so.contact_mask
+        assert np.abs(np.array(sg.q) - np.array(so.q)).max() < 1e-4
+        if task == TASK_POINTGOAL:
+            assert np.abs(np.array(sg.goal) - np.array(so.goal)).max() < 1e-6    # same Philox draws
+            assert abs(sg.potential - so.potential) < 1e-5
+
+
+@pytest.mark.parametrize("robot,task,control", [
+    (ROBOT_SOLO8, TASK_STAND, CONTROL_TORQUE), (ROBOT_SOLO8, TASK_WALK, CONTROL_PD),
+    (ROBOT_SOLO12, TASK_WALK, CONTROL_TORQUE), (ROBOT_SOLO12, TASK_POINTGOAL, CONTROL_TORQUE),
+    (ROBOT_SOLO12, TASK_STAND, CONTROL_PD)])
+def test_step_matches_oracle_resynced(gpu_device, robot, task, control):
+    """30 control steps of a random policy on 128 envs; before every step the oracle is reloaded with
+    the engine's state, so each comparison is one control step (4 sub-steps) deep."""
+    c = cfg_for(robot, task, control)
+    N = 128
+    env, orc = make(c, N, seed=3)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(0)
+    n = env.act_dim
+    dq_all, dr_all, dobs_all, done_mismatch, mask_mismatch = [], [], [], 0, 0
+    for t in range(30):
+        for i in range(N):
+            orc.set_state(i, env.get_state(i))
+        a = rng.uniform(-1.2, 1.2, size=(N, n)).astype(np.float32) * (0.3 if t < 15 else 1.0)
+        obs, rew, done, infos = env.step(torch.from_numpy(a).cuda())
+        oobs, orew, odone, oinfo = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy(); rew = rew.cpu().numpy()[:, 0]; obs = obs.cpu().numpy()
+        done_mismatch += int((done != odone).sum())
+        for i in range(N):
+            sg, so = env.get_state(i), orc.get_state(i)
+            if done[i] or odone[i]:
+                continue
+            dq_all.append(np.abs(np.array(sg.q)[:n] - np.array(so.q)[:n]).max())
+            mask_mismatch += sg.contact_mask != so.contact_mask
+        ok = (done == 0) & (odone == 0)
+        dr_all += list(np.abs(rew - orew)[ok]); dobs_all += list(np.abs(obs - oobs)[ok].max(axis=1))
+        t_info = infos.tensors
+        assert np.array_equal(t_info["episode_length"].cpu().numpy()[ok], oinfo["episode_length"][ok])
+    dq_all = np.array(dq_all)
+    assert np.median(dq_all) < 1e-4, np.median(dq_all)
+    assert np.percentile(dq_all, 90) < 1e-3 + 5e-3 * (control == CONTROL_PD), np.percentile(dq_all, 90)
+    assert np.median(dr_all) < 1e-3 and np.median(dobs_all) < 1e-3
+    assert done_mismatch <= 2 and mask_mismatch <= 0.02 * len(dq_all)
+
+
+def test_standing_trajectory_1000_steps_within_1e3_rad(gpu_device):
+    """North-star tolerance: joint angles within 1e-3 rad of the fp64 oracle over 1000 control steps
+    on fixed actions (golden fixture; settled crouch start, PD hold, sinusoidal references)."""
+    c = stand_cfg()
+    env, _ = make(c, 64)
+    env.reset()
+    s = load_state("stand_pd_start.json")
+    for i in range(64):
+        env.set_state(i, s)
+    gold = np.load(os.path.join(GOLDEN, "stand_pd_traj.npz"))
+    worst = 0.0
+    for t in range(1000):
+        a = torch.tensor(np.tile(stand_action(t), (64, 1)), dtype=torch.float32, device="cuda:0")
+        env.step(a)
+        if (t + 1) % 50 == 0:
+            k = (t + 1) // 50 - 1
+            for i in (0, 31, 63):
+                sg = env.get_state(i)
+                worst = max(worst, np.abs(np.array(sg.q) - gold["q"][k]).max())
+                assert abs(sg.pos[2] - gold["z"][k]) < 1e-3
+    assert worst < 1e-3, worst
+
+
+def test_termination_and_autoreset_semantics(gpu_device):
+    c = cfg_for(ROBOT_SOLO8, TASK_STAND, episode_length=5)
+    env, orc = make(c, 64, seed=11)
+    env.reset(); orc.reset()
+    z = torch.zeros(64, 8, device="cuda:0")
+    for t in range(5):
+        obs, rew, done, infos = env.step(z)
+        oobs, orew, odone, oinfo = orc.step(np.zeros((64, 8)))
+    assert done.sum().item() == 64 and odone.sum() == 64                      # timeout at exactly episode_length
+    d0 = infos[0]
+    assert d0["timeout"] is True and d0["success"] is True and d0["episode_length"] == 5
+    for k in ("episode_reward", "max_velocity", "min_force", "max_force", "dr/stand_rew", "dr/joint_pose_rew",
+              "dr/torque_rew", "dr/roll_pitch_balance_rew", "dr/progress_rew", "goals_reached"):
+        assert k in d0                                                         # keys read by agents/ppo/train.py:90-100
+    assert abs(d0["dr/stand_rew"] - oinfo["dr"][0][0]) < 1e-5
+    assert rew.shape == (64, 1) and done.dtype == torch.float32 and obs.dtype == torch.float32
+    s = env.get_state(0)
+    assert s.timestep == 0 and all(v == 0 for v in s.dr)                      # obs/state are post-reset
+    assert np.abs(obs.cpu().numpy() - oobs).max() < 2e-3
+    # fall -> -10, not timeout, not success
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    env, _ = make(c, 4)
+    env.reset()
+    st = env.get_state(1); st.pos[2] = 0.04
+    for leg in range(4):
+        st.q[3 * leg + 1] = np.pi / 2; st.q[3 * leg + 2] = 0.0
+    env.set_state(1, st)
+    obs, rew, done, infos = env.step(torch.zeros(4, 12, device="cuda:0"))
+    assert done[1].item() == 1.0 and rew[1, 0].item() == -10.0
+    assert infos[1]["timeout"] is False and infos[1]["success"] is False and done[0].item() == 0.0
+
+
+def test_step_before_reset_is_an_error(gpu_device):
+    from solorl_amd.vec_env import SoloVecEnv
+    from solorl_amd._native import SoloRLError
+    env = SoloVecEnv(cfg_for(ROBOT_SOLO12, TASK_WALK), 8, device="cuda:0")
+    with pytest.raises(SoloRLError, match="reset"):                            # baseEnv.py:43
+        env.step(torch.zeros(8, 12, device="cuda:0"))
+    with pytest.raises(AssertionError):                                        # solo.py:226
+        env.reset(); env.step(torch.zeros(8, 11, device="cuda:0"))
+
+
+def test_full_size_properties(gpu_device):
+    """BASELINE size (4096 envs, Solo12 walk): determinism, finiteness, episode accounting and env
+    independence -- properties that do not need the oracle to finish 4096 x 450 steps."""
+    from solorl_amd.vec_env import SoloVecEnv
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    N = 4096
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    acts = torch.rand((32, N, 12), device="cuda:0", generator=g) * 2 - 1
+    outs = []
+    for rep in range(2):
+        env = SoloVecEnv(c, N, device="cuda:0", seed=9)
+        o = env.reset()
+        n_done = torch.zeros(N, device="cuda:0"); ep_len_ok = True
+        for t in range(450):
+            o, r, d, info = env.step_inplace(acts[t % 32])
+            assert torch.isfinite(o).all() and torch.isfinite(r).all()
+            n_done += d.float()
+            if d.any():
+                el = info["episode_length"][d.bool()]
+                ep_len_ok &= bool(((el >= 1) & (el <= 400)).all())
+        outs.append((o.clone(), r.clone(), n_done.clone()))
+        assert ep_len_ok and (n_done >= 1).all()            # every env ends at least once within 450 steps (T=400)
+        assert info["nan_reset"].sum().item() == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # bitwise reproducible
+    # env independence / sharding: envs 2048.. of the big batch == a shard created with env_id_offset
+    env_a = SoloVecEnv(c, N, device="cuda:0", seed=9)
+    env_b = SoloVecEnv(c, N // 2, device="cuda:0", seed=9, env_id_offset=N // 2)
+    oa, ob = env_a.reset(), env_b.reset()
+    for t in range(40):
+        oa, _, _, _ = env_a.step_inplace(acts[t % 32]); ob, _, _, _ = env_b.step_inplace(acts[t % 32][N // 2:].contiguous())
+    assert torch.equal(oa[N // 2:], ob)
+
+
+def test_pointgoal_bookkeeping_full_size(gpu_device):
+    from solorl_amd.vec_env import SoloVecEnv
+    c = cfg_for(ROBOT_SOLO12, TASK_POINTGOAL)
+    env = SoloVecEnv(c, 4096, device="cuda:0", seed=2)
+    o = env.reset()
+    goal = o[:, 40:42] * 2
+    assert ((goal.abs() >= 1.0) & (goal.abs() < 2.0)).all()                   # solo.py:327-330
+    assert (goal > 0).any() and (goal < 0).any()
+    env.increment_curriculum()
+    a = torch.zeros(4096, 12, device="cuda:0")
+    for t in range(60):
+        o, r, d, info = env.step_inplace(a)
+    goal = o[:, 40:42] * 2
+    assert (goal.abs() < 3.0).all() and (goal.abs() >= 2.0).any()             # goal_radius 2 -> 3 after curriculum
