@@ -11,7 +11,13 @@
 //     3 (2) joints of that leg:  J.dV = Jh.w + JL.yL  with  Jh = force transmitted to the base,
 //     w = base delta-velocity, yL = leg delta-rates with the base held fixed;
 //   * rows live in LDS ([row][16-byte chunk][lane], conflict-free b128 accesses), only the base
-//     accumulator w stays in registers during the PGS sweep.
+//     accumulator w stays in registers during the PGS sweep;
+//   * register diet: the sub-step is a sequence of NON-INLINED phase functions that hand off through
+//     an explicit per-lane context (private memory), so every phase -- above all the PGS sweep --
+//     gets its own register allocation and nothing is spilled inside a hot loop.  Legs are
+//     processed one at a time; of a finished leg only its 3x6 response matrix G
+//     (dq_leg = y - G w, qdd_leg = qdd0 - G a_base) survives, its constraint rows are parked
+//     half-built in LDS and completed by ONE generic loop once the base inverse inertia is known.
 #pragma once
 #include <utility>
 
@@ -56,46 +62,56 @@ template <typename T, int NQ> struct PhysState {
 template <typename T> struct JointF { SV<T> S, U, c; T Dinv, u; };
 
 // ---------------------------------------------------------------- LDS row storage
-// chunk = 16 bytes; a row's core is ROW_CORE values of T.
+// One row = ROW_CORE values of T, stored [row][lane][ROW_CORE]: a lane's row is one 80-byte (fp32)
+// record read with five ds_read_b128 at immediate offsets.  80 B = 20 dwords and 5 is coprime with
+// 16, so the 16 lanes of every b128 lane group hit 64 distinct banks (conflict-free).
+// The struct holds only (lanes, lane): every phase function re-derives its pointers from the
+// `extern __shared__` symbol so they stay address-space-3 (ds_* instructions) across the
+// non-inlined phase boundaries -- generic pointers would turn every access into a FLAT one.
+#ifndef SOLO_HOST_SHIM
+extern __shared__ __attribute__((aligned(16))) unsigned char solo_smem[];
+#endif
 template <typename T> struct RowLds {
-  static constexpr int PER = 16 / sizeof(T);            // values per chunk (4 float / 2 double)
+  static constexpr int PER = 16 / sizeof(T);            // values per 16-byte chunk (4 float / 2 double)
   static constexpr int NCH = ROW_CORE / PER;            // 5 / 10
   using Chunk = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
-  Chunk* core;   // [MAX_ROWS][NCH][LANES]
-  T* mu;         // [MAX_ROWS][LANES]
-  T* lam;        // [MAX_ROWS][LANES]
-  int* meta;     // [MAX_ROWS][LANES]   bits 0-4 parent row, 5-6 leg, 7 is_friction
-  T* y;          // [12][LANES]
   int lanes, lane;
+#ifdef SOLO_HOST_SHIM
+  unsigned char* base;
+  SD unsigned char* smem() const { return base; }
+#else
+  SD unsigned char* smem() const { return solo_smem; }
+#endif
+  SD Chunk* core() const { return reinterpret_cast<Chunk*>(smem()); }   // [MAX_ROWS][lanes][NCH]
+  SD T* mu() const { return reinterpret_cast<T*>(smem() + (size_t)MAX_ROWS * lanes * ROW_CORE * sizeof(T)); }
+  SD T* lam() const { return mu() + MAX_ROWS * lanes; }
+  SD T* y() const { return lam() + MAX_ROWS * lanes; }     // [12][lanes] leg delta-rates, base fixed
+  SD T* qs() const { return y() + 12 * lanes; }            // [12][lanes] unconstrained joint rates u*
+  SD int* meta() const { return reinterpret_cast<int*>(qs() + 12 * lanes); }
+  // meta bits: 0-4 parent row, 5-6 leg, 7 is_friction, 8-9 direction (0 z, 1 x, 2 y, 3 joint)
 
   SD void store_core(int r, const T (&v)[ROW_CORE]) const {
+    Chunk* p = core() + (r * lanes + lane) * NCH;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       Chunk ch;
       if constexpr (sizeof(T) == 4) ch = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
       else ch = make_double2(v[2 * c], v[2 * c + 1]);
-      core[(r * NCH + c) * lanes + lane] = ch;
+      p[c] = ch;
     }
   }
   SD void load_core(int r, T (&v)[ROW_CORE]) const {
+    const Chunk* p = core() + (r * lanes + lane) * NCH;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      Chunk ch = core[(r * NCH + c) * lanes + lane];
+      Chunk ch = p[c];
       if constexpr (sizeof(T) == 4) { v[4 * c] = ch.x; v[4 * c + 1] = ch.y; v[4 * c + 2] = ch.z; v[4 * c + 3] = ch.w; }
       else { v[2 * c] = ch.x; v[2 * c + 1] = ch.y; }
     }
   }
   static constexpr size_t bytes(int lanes_) {
-    return (size_t)MAX_ROWS * NCH * lanes_ * 16 + (size_t)MAX_ROWS * lanes_ * (2 * sizeof(T) + sizeof(int)) +
-           (size_t)12 * lanes_ * sizeof(T);
-  }
-  SD void carve(unsigned char* base, int lanes_, int lane_) {
-    lanes = lanes_; lane = lane_;
-    core = reinterpret_cast<Chunk*>(base); base += (size_t)MAX_ROWS * NCH * lanes * 16;
-    mu = reinterpret_cast<T*>(base); base += (size_t)MAX_ROWS * lanes * sizeof(T);
-    lam = reinterpret_cast<T*>(base); base += (size_t)MAX_ROWS * lanes * sizeof(T);
-    y = reinterpret_cast<T*>(base); base += (size_t)12 * lanes * sizeof(T);
-    meta = reinterpret_cast<int*>(base);
+    return (size_t)MAX_ROWS * lanes_ * ROW_CORE * sizeof(T) + (size_t)MAX_ROWS * lanes_ * (2 * sizeof(T) + sizeof(int)) +
+           (size_t)24 * lanes_ * sizeof(T);
   }
 };
 
@@ -146,17 +162,15 @@ template <typename T> SD void sincos_t(T x, T& s, T& c) {
   if constexpr (sizeof(T) == 4) sincosf(x, &s, &c); else sincos(x, &s, &c);
 }
 
-// ---------------------------------------------------------------- leg: FK + ABA passes 1 and 2
-template <typename T, int ROBOT, int L>
-SD void leg_inward(const M3<T>& R0, SV<T> v0, const T* q, const T* qd, const T* tau, T kd,
-                   JointF<T> (&jf)[Robot<ROBOT>::NJ], ABI<T>& Ibase, SV<T>& pbase, V3<T>& kneeP, V3<T>& footP) {
+// ---------------------------------------------------------------- leg kinematics (shared)
+// frames of the NJ moving links of leg L from cached sin/cos; calls f(k, R_k, o_k, a_k) per joint.
+template <typename T, int ROBOT, int L, typename F>
+SD void leg_frames(const M3<T>& R0, const T* sn, const T* cs, F&& f) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   constexpr int L0 = 1 + L * (NJ + 1);
   M3<T> Rp = R0;
   V3<T> op = mk(T(0), T(0), T(0));
-  SV<T> vp = v0;
-  RBI<T> Ik[NJ]; SV<T> pk[NJ]; SV<T> Sk[NJ], ck[NJ];
   static_for<NJ>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr solorl_link_data LK = RB::MD.links[L0 + k];
@@ -164,191 +178,101 @@ SD void leg_inward(const M3<T>& R0, SV<T> v0, const T* q, const T* qd, const T* 
     static_assert(LK.axis[2] == 0.0 && LK.jtype == 0, "revolute about x or y expected");
     V3<T> o = addc(op, Rp, LK.jorigin[0], LK.jorigin[1], LK.jorigin[2]);
     V3<T> a = AX == 0 ? Rp.c0 : Rp.c1;
-    SV<T> S{a, cross(o, a)};
-    T s, c; sincos_t(q[LK.dof], s, c);
-    M3<T> R = rot_axis<AX>(Rp, c, s);
-    SV<T> vj = S * qd[LK.dof];
-    SV<T> v = vp + vj;
-    Sk[k] = S; ck[k] = crm(vp, vj);
-    V3<T> cw = addc(o, R, LK.com[0], LK.com[1], LK.com[2]);
-    link_terms(R, cw, T(LK.mass), T(LK.inertia_box[0]), T(LK.inertia_box[1]), T(LK.inertia_box[2]), v, kd, Ik[k], pk[k]);
+    M3<T> R = rot_axis<AX>(Rp, cs[LK.dof], sn[LK.dof]);
+    f(kc, R, o, a);
+    Rp = R; op = o;
+  });
+}
+
+// knee and foot support points of leg L (relative to the base origin)
+template <typename T, int ROBOT, int L>
+SD void leg_prim_points(const M3<T>& R0, const T* sn, const T* cs, V3<T>& kneeP, V3<T>& footP) {
+  using RB = Robot<ROBOT>;
+  constexpr int NJ = RB::NJ;
+  constexpr int L0 = 1 + L * (NJ + 1);
+  leg_frames<T, ROBOT, L>(R0, sn, cs, [&](auto kc, const M3<T>& R, V3<T> o, V3<T>) {
+    constexpr int k = decltype(kc)::value;
     if constexpr (k == NJ - 2) {  // knee disc sits on the upper leg
       constexpr solorl_prim_data PR = RB::MD.prims[12 + 2 * L];
       static_assert(PR.link == L0 + k && PR.axis == 1, "knee primitive layout");
       kneeP = disc_point(R, addc(o, R, PR.center[0], PR.center[1], PR.center[2]), T(PR.radius));
     }
-    if constexpr (k == NJ - 1) {  // foot: fixed child of the last link, same axes and velocity
+    if constexpr (k == NJ - 1) {  // foot: fixed child of the last link
       constexpr solorl_link_data FT = RB::MD.links[L0 + NJ];
-      static_assert(FT.jtype == 1, "foot must be a fixed joint");
-      V3<T> of = addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]);
-      V3<T> cf = addc(of, R, FT.com[0], FT.com[1], FT.com[2]);
-      RBI<T> If; SV<T> pf;
-      link_terms(R, cf, T(FT.mass), T(FT.inertia_box[0]), T(FT.inertia_box[1]), T(FT.inertia_box[2]), v, kd, If, pf);
-      add(Ik[k], If); pk[k] = pk[k] + pf;
       constexpr solorl_prim_data PR = RB::MD.prims[13 + 2 * L];
-      static_assert(PR.link == L0 + NJ && PR.axis == 1 && PR.center[0] == 0.0 && PR.center[1] == 0.0 && PR.center[2] == 0.0,
-                    "foot primitive layout");
-      footP = disc_point(R, of, T(PR.radius));
+      static_assert(FT.jtype == 1 && PR.link == L0 + NJ && PR.axis == 1 && PR.center[0] == 0.0 && PR.center[1] == 0.0 &&
+                    PR.center[2] == 0.0, "foot primitive layout");
+      footP = disc_point(R, addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]), T(PR.radius));
     }
-    Rp = R; op = o; vp = v;
-  });
-  // pass 2: outermost joint first
-  ABI<T> IA = to_abi(Ik[NJ - 1]);
-  SV<T> pA = pk[NJ - 1];
-  static_for<NJ>([&](auto kc) {
-    constexpr int k = NJ - 1 - decltype(kc)::value;
-    constexpr int dof = RB::MD.links[L0 + k].dof;
-    SV<T> S = Sk[k];
-    SV<T> U = mul(IA, S);
-    T Dinv = T(1) / dot(S, U);
-    T u = tau[dof] - dot(S, pA);
-    jf[k].S = S; jf[k].U = U; jf[k].c = ck[k]; jf[k].Dinv = Dinv; jf[k].u = u;
-    rank1_sub(IA, U, Dinv);
-    SV<T> pa = pA + mul(IA, ck[k]) + U * (u * Dinv);
-    if constexpr (k > 0) { add(IA, Ik[k - 1]); pA = pk[k - 1] + pa; }
-    else { add(Ibase, IA); pbase = pbase + pa; }
   });
 }
 
 template <typename T> SD T clampv(T x, T lim) { return x > lim ? lim : (x < -lim ? -lim : x); }
 
-// ---------------------------------------------------------------- constraint-row construction
-// Builds one row for leg L: external unit wrench F applied to the link that is DEPTH joints away
-// from the base (DEPTH = 0: base itself), or a unit joint torque (LIMJ >= 0, sign sg) at joint LIMJ.
-template <typename T, int NJ, int DEPTH, int LIMJ>
-SD void build_row(SV<T> F, T sg, const JointF<T> (&jf)[NJ], const Sym6<T>& Lam, SV<T> ub, const T* qdl /*leg rates*/,
-                  T (&core)[ROW_CORE], T& denom, T& rel) {
-  T t[NJ], JL[3] = {T(0), T(0), T(0)}, Y[3] = {T(0), T(0), T(0)};
-  SV<T> f = F;
-  static_for<NJ>([&](auto kc) {
-    constexpr int k = NJ - 1 - decltype(kc)::value;
-    if constexpr (LIMJ >= 0) {
-      if constexpr (k > LIMJ) t[k] = T(0);
-      else if constexpr (k == LIMJ) { t[k] = sg; JL[k] = sg; f = jf[k].U * (-sg * jf[k].Dinv); }
-      else { t[k] = dot(jf[k].S, f); f = fma6(jf[k].U, -t[k] * jf[k].Dinv, f); }
-    } else {
-      if constexpr (k >= DEPTH) t[k] = T(0);
-      else { t[k] = dot(jf[k].S, f); JL[k] = dot(jf[k].S, F); f = fma6(jf[k].U, -t[k] * jf[k].Dinv, f); }
-    }
-  });
-  if constexpr (DEPTH > 0 || LIMJ >= 0) {  // leg response with the base held fixed
-    SV<T> dv = zero6<T>();
-    static_for<NJ>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      T yk;
-      if constexpr (k == 0) yk = t[0] * jf[0].Dinv; else yk = (t[k] - dot(jf[k].U, dv)) * jf[k].Dinv;
-      Y[k] = yk;
-      if constexpr (k < NJ - 1) dv = fma6(jf[k].S, yk, dv);
-    });
-  }
-  SV<T> W = mul(Lam, f);
-  denom = dot(f, W);
-  rel = (LIMJ >= 0) ? T(0) : dot(F, ub);
-#pragma unroll
-  for (int k = 0; k < NJ; k++) { denom += JL[k] * Y[k]; rel += JL[k] * qdl[k]; }
-  core[0] = f.a.x; core[1] = f.a.y; core[2] = f.a.z; core[3] = f.l.x; core[4] = f.l.y; core[5] = f.l.z;
-  core[6] = JL[0]; core[7] = JL[1]; core[8] = JL[2];
-  core[9] = W.a.x; core[10] = W.a.y; core[11] = W.a.z; core[12] = W.l.x; core[13] = W.l.y; core[14] = W.l.z;
-  core[15] = Y[0]; core[16] = Y[1]; core[17] = Y[2];
-}
+// what survives of a processed leg
+template <typename T, int NJ> struct LegResp {
+  SV<T> G[NJ];   // dq_k = y_k - G_k . w   (w = base delta-velocity);  qdd_k = qdd0_k - G_k . a_base
+  T qdd0[NJ];
+};
 
-// the three rows (normal z, friction x, friction y) of one contact point P (relative to the base
-// origin) on leg L at chain depth DEPTH; writes them to LDS and applies the warm start.
-template <typename T, int NJ, int DEPTH>
-SD void contact_rows(V3<T> P, T dist, T mu, T lam0, int leg, int slot_n, int slot_f, const JointF<T> (&jf)[NJ],
-                     const Sym6<T>& Lam, SV<T> ub, const T* qdl, const PhysParams<T>& pp, const RowLds<T>& lds,
-                     SV<T>& w, T (&yl)[3]) {
-  static_for<3>([&](auto dc) {
-    constexpr int d = decltype(dc)::value;   // 0: normal (z), 1: friction x, 2: friction y
-    V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
-    SV<T> F{cross(P, u), u};
-    T core[ROW_CORE], denom, rel;
-    build_row<T, NJ, DEPTH, -1>(F, T(0), jf, Lam, ub, qdl, core, denom, rel);
-    T dinv = T(1) / denom, rhs;
-    if constexpr (d == 0) {
-      T pen = dist + pp.slop, pos = T(0), vel = -rel;
-      if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * pp.erp * pp.inv_dt;
-      rhs = (pos + vel) * dinv;
-    } else rhs = -rel * dinv;
-    core[18] = rhs; core[19] = dinv;
-    int slot = d == 0 ? slot_n : slot_f + (d - 1);
-    lds.store_core(slot, core);
-    lds.mu[slot * lds.lanes + lds.lane] = mu;
-    lds.lam[slot * lds.lanes + lds.lane] = d == 0 ? lam0 : T(0);
-    lds.meta[slot * lds.lanes + lds.lane] = (d == 0 ? 0 : (slot_n | 128)) | (leg << 5);
-    if constexpr (d == 0) {  // warm start: dV += M^-1 J^T lam0
-      w.a = fma3(mk(core[9], core[10], core[11]), lam0, w.a);
-      w.l = fma3(mk(core[12], core[13], core[14]), lam0, w.l);
-      yl[0] += core[15] * lam0; yl[1] += core[16] * lam0; yl[2] += core[17] * lam0;
-    }
-  });
-}
-
-// ---------------------------------------------------------------- one physics sub-step
-// tau: joint torques applied during this sub-step.  lam_prev: per-primitive warm-start impulses
-// (global memory, stride = nstride).  Returns the contact bit mask.
-template <typename T, int ROBOT>
-SD int substep(PhysState<T, Robot<ROBOT>::NQ>& st, const T* tau, const PhysParams<T>& pp, T* lam_prev, size_t nstride,
-               const RowLds<T>& lds) {
-  using RB = Robot<ROBOT>;
-  constexpr int NJ = RB::NJ, NQ = RB::NQ;
-  const T dt = pp.dt;
-  M3<T> R0 = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
-  SV<T> v0{st.w, st.v};
-
-  // ---- stage A: base link + the four legs (FK, velocities, inertias, ABA passes 1-2)
-  JointF<T> jf[4][NJ];
+// per-lane hand-off between the phases of one sub-step (private memory)
+template <typename T, int ROBOT> struct SubCtx {
+  static constexpr int NJ = Robot<ROBOT>::NJ, NQ = Robot<ROBOT>::NQ;
+  PhysState<T, NQ> ps;
+  T tau[NQ];
+  T sn[NQ], cs[NQ];
+  M3<T> R0;
   V3<T> kneeP[4], footP[4];
+  T dist[NPRIM];
+  int mask, nc, nlim_total, nlim;
   ABI<T> Ibase; SV<T> pbase;
-  {
-    constexpr solorl_link_data B = RB::MD.links[0];
-    static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
-    RBI<T> Ib;
-    link_terms(R0, mk(T(0), T(0), T(0)), T(B.mass), T(B.inertia_box[0]), T(B.inertia_box[1]), T(B.inertia_box[2]), v0,
-               pp.damping, Ib, pbase);
-    Ibase = to_abi(Ib);
-  }
-  static_for<4>([&](auto lc) {
-    constexpr int L = decltype(lc)::value;
-    leg_inward<T, ROBOT, L>(R0, v0, st.q, st.qd, tau, pp.damping, jf[L], Ibase, pbase, kneeP[L], footP[L]);
-  });
+  LegResp<T, NJ> LR[4];
+  SV<T> ub; T qds[NQ];
+  SV<T> w; T y[4][3]; T lam_n[8];
+};
 
-  // ---- stage B: base acceleration (gravity via the accelerating-frame trick), pass 3, u* = u + dt*udot
-  Sym6<T> Lam = spd_inverse(Ibase);
-  SV<T> a0 = mul(Lam, pbase) * T(-1);
-  T qds[NQ];
-  static_for<4>([&](auto lc) {
-    constexpr int L = decltype(lc)::value;
-    SV<T> ap = a0;
-    static_for<NJ>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const JointF<T>& J = jf[L][k];
-      SV<T> apc = ap + J.c;
-      T qdd = (J.u - dot(J.U, apc)) * J.Dinv;
-      if constexpr (k < NJ - 1) ap = fma6(J.S, qdd, apc);
-      qds[L * NJ + k] = clampv(st.qd[L * NJ + k] + dt * qdd, pp.vmax);
-    });
-  });
-  V3<T> vdot = a0.l + cross(st.w, st.v); vdot.z -= pp.gravity;
-  SV<T> ub;
-  ub.a = mk(clampv(st.w.x + dt * a0.a.x, pp.vmax), clampv(st.w.y + dt * a0.a.y, pp.vmax), clampv(st.w.z + dt * a0.a.z, pp.vmax));
-  ub.l = mk(clampv(st.v.x + dt * vdot.x, pp.vmax), clampv(st.v.y + dt * vdot.y, pp.vmax), clampv(st.v.z + dt * vdot.z, pp.vmax));
+// park one half-built row in LDS: f0 (force transmitted to the base), JL (raw joint torques),
+// Y (leg response, base fixed), the contact point P and penetration for the finishing loop.
+template <typename T>
+SD void park_row(const RowLds<T>& lds, int slot, SV<T> f0, const T (&JL)[3], const T (&Y)[3], V3<T> P, T pen, T lam0, T mu,
+                 int meta) {
+  T core[ROW_CORE];
+  core[0] = f0.a.x; core[1] = f0.a.y; core[2] = f0.a.z; core[3] = f0.l.x; core[4] = f0.l.y; core[5] = f0.l.z;
+  core[6] = JL[0]; core[7] = JL[1]; core[8] = JL[2];
+  core[9] = P.x; core[10] = P.y; core[11] = P.z; core[12] = pen; core[13] = lam0; core[14] = T(0);
+  core[15] = Y[0]; core[16] = Y[1]; core[17] = Y[2]; core[18] = T(0); core[19] = T(0);
+  lds.store_core(slot, core);
+  lds.mu()[slot * lds.lanes + lds.lane] = mu;
+  lds.meta()[slot * lds.lanes + lds.lane] = meta;
+}
 
-  // ---- stage C: collision detection (start-of-step pose) and constraint rows
-  T dist[NPRIM]; V3<T> PP[NPRIM];
+// ---------------------------------------------------------------- phase 1: collision detection
+// start-of-step pose (K1, K6'): support points, contact mask, MAX_CONTACTS cap, row counts
+template <typename T, int ROBOT>
+SNI void phase_detect(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp) {
+  using RB = Robot<ROBOT>;
+  constexpr int NQ = RB::NQ;
+  const PhysState<T, NQ>& st = C.ps;
+  const M3<T> R0 = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
+  C.R0 = R0;
+  T sn[NQ], cs[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; j++) { sincos_t(st.q[j], sn[j], cs[j]); C.sn[j] = sn[j]; C.cs[j] = cs[j]; }
+  T dist[NPRIM];
   int mask = 0;
   static_for<12>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr solorl_prim_data PR = RB::MD.prims[p];
     static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
-    PP[p] = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
-    dist[p] = st.pos.z + PP[p].z;
+    dist[p] = st.pos.z + R0.c0.z * T(PR.center[0]) + R0.c1.z * T(PR.center[1]) + R0.c2.z * T(PR.center[2]);
     if (dist[p] < T(PR.margin)) mask |= 1 << p;
   });
   static_for<4>([&](auto lc) {
     constexpr int L = decltype(lc)::value;
-    PP[12 + 2 * L] = kneeP[L]; PP[13 + 2 * L] = footP[L];
-    dist[12 + 2 * L] = st.pos.z + kneeP[L].z; dist[13 + 2 * L] = st.pos.z + footP[L].z;
+    V3<T> kneeP, footP;
+    leg_prim_points<T, ROBOT, L>(R0, sn, cs, kneeP, footP);
+    C.kneeP[L] = kneeP; C.footP[L] = footP;
+    dist[12 + 2 * L] = st.pos.z + kneeP.z; dist[13 + 2 * L] = st.pos.z + footP.z;
     if (dist[12 + 2 * L] < T(RB::MD.prims[12 + 2 * L].margin)) mask |= 1 << (12 + 2 * L);
     if (dist[13 + 2 * L] < T(RB::MD.prims[13 + 2 * L].margin)) mask |= 1 << (13 + 2 * L);
   });
@@ -365,109 +289,377 @@ SD int substep(PhysState<T, Robot<ROBOT>::NQ>& st, const T* tau, const PhysParam
     });
     mask = keep;
   }
-  const int nc = __popc(mask);
-
-  SV<T> w = zero6<T>();
-  T y[4][3];
 #pragma unroll
-  for (int L = 0; L < 4; L++) { y[L][0] = T(0); y[L][1] = T(0); y[L][2] = T(0); }
-  int nlim = 0;
-  static_for<4>([&](auto lc) {          // joint-limit rows (K5): first MAX_LIMITS in joint order
-    constexpr int L = decltype(lc)::value;
+  for (int p = 0; p < NPRIM; p++) C.dist[p] = dist[p];
+  int nl = 0;   // limit rows come first: their count fixes the contact slots
+#pragma unroll
+  for (int j = 0; j < NQ; j++) {
+    nl += (st.q[j] + pp.qlim < T(LIMIT_WINDOW)) ? 1 : 0;
+    nl += (pp.qlim - st.q[j] < T(LIMIT_WINDOW)) ? 1 : 0;
+  }
+  C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
+  // base link terms start the articulated-inertia accumulation
+  constexpr solorl_link_data B = RB::MD.links[0];
+  static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
+  RBI<T> Ib; SV<T> pb;
+  link_terms(R0, mk(T(0), T(0), T(0)), T(B.mass), T(B.inertia_box[0]), T(B.inertia_box[1]), T(B.inertia_box[2]),
+             SV<T>{st.w, st.v}, pp.damping, Ib, pb);
+  C.Ibase = to_abi(Ib); C.pbase = pb;
+}
+
+// ---------------------------------------------------------------- phase 2 (x4): one leg
+// FK + ABA passes 1-2, leg response (G, qdd0), parked limit and contact rows of this leg
+template <typename T, int ROBOT, int L>
+SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const RowLds<T> lds) {
+  using RB = Robot<ROBOT>;
+  constexpr int NJ = RB::NJ;
+  constexpr int L0 = 1 + L * (NJ + 1);
+  const T kd = pp.damping;
+  const M3<T> R0 = C.R0;
+  SV<T> vp{C.ps.w, C.ps.v};
+  T sn[NJ], cs[NJ], qd[NJ], q[NJ], tau[NJ];
+#pragma unroll
+  for (int k = 0; k < NJ; k++) {
+    sn[k] = C.sn[L * NJ + k]; cs[k] = C.cs[L * NJ + k]; qd[k] = C.ps.qd[L * NJ + k]; q[k] = C.ps.q[L * NJ + k];
+    tau[k] = C.tau[L * NJ + k];
+  }
+  RBI<T> Ik[NJ]; SV<T> pk[NJ]; SV<T> Sk[NJ], ck[NJ];
+  {
+    M3<T> Rp = R0;
+    V3<T> op = mk(T(0), T(0), T(0));
     static_for<NJ>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      const T qj = st.q[L * NJ + k];
-#pragma unroll
-      for (int side = 0; side < 2; side++) {
-        T pen = side == 0 ? qj + pp.qlim : pp.qlim - qj;
-        if (pen < T(LIMIT_WINDOW) && nlim < MAX_LIMITS) {
-          T sg = side == 0 ? T(1) : T(-1);
-          T core[ROW_CORE], denom, rel;
-          build_row<T, NJ, 0, k>(zero6<T>(), sg, jf[L], Lam, ub, &qds[L * NJ], core, denom, rel);
-          T dinv = T(1) / denom, pos = T(0), vel = -rel;
-          if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * pp.erp * pp.inv_dt;
-          core[18] = (pos + vel) * dinv; core[19] = dinv;
-          lds.store_core(nlim, core);
-          lds.mu[nlim * lds.lanes + lds.lane] = T(0);
-          lds.lam[nlim * lds.lanes + lds.lane] = T(0);
-          lds.meta[nlim * lds.lanes + lds.lane] = L << 5;
-          nlim++;
-        }
+      constexpr solorl_link_data LK = RB::MD.links[L0 + k];
+      constexpr int AX = LK.axis[0] != 0.0 ? 0 : 1;
+      static_assert(LK.dof == L * NJ + k, "dof order");
+      V3<T> o = addc(op, Rp, LK.jorigin[0], LK.jorigin[1], LK.jorigin[2]);
+      V3<T> a = AX == 0 ? Rp.c0 : Rp.c1;
+      M3<T> R = rot_axis<AX>(Rp, cs[k], sn[k]);
+      SV<T> S{a, cross(o, a)};
+      SV<T> vj = S * qd[k];
+      SV<T> v = vp + vj;
+      Sk[k] = S; ck[k] = crm(vp, vj);
+      V3<T> cw = addc(o, R, LK.com[0], LK.com[1], LK.com[2]);
+      link_terms(R, cw, T(LK.mass), T(LK.inertia_box[0]), T(LK.inertia_box[1]), T(LK.inertia_box[2]), v, kd, Ik[k], pk[k]);
+      if constexpr (k == NJ - 1) {  // foot: fixed child of the last link, same axes and velocity
+        constexpr solorl_link_data FT = RB::MD.links[L0 + NJ];
+        V3<T> of = addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]);
+        V3<T> cf = addc(of, R, FT.com[0], FT.com[1], FT.com[2]);
+        RBI<T> If; SV<T> pf;
+        link_terms(R, cf, T(FT.mass), T(FT.inertia_box[0]), T(FT.inertia_box[1]), T(FT.inertia_box[2]), v, kd, If, pf);
+        add(Ik[k], If); pk[k] = pk[k] + pf;
       }
+      Rp = R; op = o; vp = v;
+    });
+  }
+  // pass 2: outermost joint first
+  SV<T> Uk[NJ]; T Dk[NJ], uk[NJ];
+  {
+    ABI<T> IA = to_abi(Ik[NJ - 1]);
+    SV<T> pA = pk[NJ - 1];
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = NJ - 1 - decltype(kc)::value;
+      SV<T> S = Sk[k];
+      SV<T> U = mul(IA, S);
+      T Dinv = T(1) / dot(S, U);
+      T u = tau[k] - dot(S, pA);
+      Uk[k] = U; Dk[k] = Dinv; uk[k] = u;
+      rank1_sub(IA, U, Dinv);
+      SV<T> pa = pA + mul(IA, ck[k]) + U * (u * Dinv);
+      if constexpr (k > 0) { add(IA, Ik[k - 1]); pA = pk[k - 1] + pa; }
+      else { ABI<T> Ib = C.Ibase; add(Ib, IA); C.Ibase = Ib; C.pbase = C.pbase + pa; }
+    });
+  }
+  // leg response: qdd0 (base acceleration zero), G rows and Minv = M_LL^-1 columns from unit joint torques
+  LegResp<T, NJ> LR;
+  {
+    SV<T> ap = zero6<T>();
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      SV<T> apc = ap + ck[k];
+      T qdd = (uk[k] - dot(Uk[k], apc)) * Dk[k];
+      LR.qdd0[k] = qdd;
+      if constexpr (k < NJ - 1) ap = fma6(Sk[k], qdd, apc);
+    });
+  }
+  T Minv[3][3];   // Minv[row][col]
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Minv[i][j] = T(0);
+  static_for<NJ>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;   // unit torque at joint j
+    T t[NJ];
+    SV<T> f = Uk[j] * (-Dk[j]);
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = NJ - 1 - decltype(kc)::value;
+      if constexpr (k > j) t[k] = T(0);
+      else if constexpr (k == j) t[k] = T(1);
+      else { t[k] = dot(Sk[k], f); f = fma6(Uk[k], -t[k] * Dk[k], f); }
+    });
+    LR.G[j] = f * T(-1);
+    SV<T> dv = zero6<T>();
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      T yk;
+      if constexpr (k == 0) yk = t[0] * Dk[0]; else yk = (t[k] - dot(Uk[k], dv)) * Dk[k];
+      Minv[k][j] = yk;
+      if constexpr (k < NJ - 1) dv = fma6(Sk[k], yk, dv);
     });
   });
-  static_for<NPRIM>([&](auto pc) {
-    constexpr int p = decltype(pc)::value;
-    constexpr solorl_prim_data PR = RB::MD.prims[p];
-    T lam0 = T(0);
-    if ((mask >> p) & 1) {
-      const int cidx = __popc(mask & ((1 << p) - 1));
-      const int slot_n = nlim + cidx, slot_f = nlim + nc + 2 * cidx;
-      lam0 = pp.warm * lam_prev[(size_t)p * nstride];
-      if constexpr (p < 12) {
-        T dummy[3] = {T(0), T(0), T(0)};
-        contact_rows<T, NJ, 0>(PP[p], dist[p], T(PR.friction), lam0, 0, slot_n, slot_f, jf[0], Lam, ub, &qds[0], pp, lds, w, dummy);
-      } else {
-        constexpr int L = (p - 12) / 2;
-        constexpr int DEPTH = ((p - 12) % 2 == 0) ? NJ - 1 : NJ;
-        contact_rows<T, NJ, DEPTH>(PP[p], dist[p], T(PR.friction), lam0, L, slot_n, slot_f, jf[L], Lam, ub, &qds[L * NJ], pp, lds, w, y[L]);
+  C.LR[L] = LR;
+  // joint-limit rows of this leg (K5): first MAX_LIMITS in joint order across the robot
+  int nlim = C.nlim;
+  static_for<NJ>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
+      if (pen < T(LIMIT_WINDOW) && nlim < MAX_LIMITS) {
+        T sg = side == 0 ? T(1) : T(-1);
+        T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
+        JL[k] = sg;
+        park_row(lds, nlim, LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8) | ((3 * L) << 10));
+        nlim++;
       }
     }
   });
-  const int nrows = nlim + 3 * nc;
+  C.nlim = nlim;
+  // contact rows of this leg's primitives: knee (chain depth NJ-1) and foot (depth NJ)
+  const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
+  static_for<2>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int p = 12 + 2 * L + i;
+    constexpr int DEPTH = i == 0 ? NJ - 1 : NJ;
+    constexpr solorl_prim_data PR = RB::MD.prims[p];
+    if ((mask >> p) & 1) {
+      const int cidx = __popc(mask & ((1 << p) - 1));
+      const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
+      const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
+      const T pen = C.dist[p] + pp.slop;
+      const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
+      static_for<3>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;   // 0: normal (z), 1: friction x, 2: friction y
+        V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
+        SV<T> F{cross(P, u), u};
+        T JL[3] = {T(0), T(0), T(0)}, Y[3];
+        SV<T> f0 = F;
+        static_for<DEPTH>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          JL[k] = dot(Sk[k], F);
+          f0 = fma6(LR.G[k], -JL[k], f0);
+        });
 #pragma unroll
-  for (int L = 0; L < 4; L++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) lds.y[(L * 3 + k) * lds.lanes + lds.lane] = y[L][k];
+        for (int r = 0; r < 3; r++) Y[r] = Minv[r][0] * JL[0] + Minv[r][1] * JL[1] + Minv[r][2] * JL[2];
+        park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0), T(PR.friction),
+                 (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8) | ((3 * L) << 10));
+      });
+    }
+  });
+}
 
-  // ---- stage D: projected Gauss-Seidel (K7): limits, normals, then friction rows
-  for (int it = 0; it < pp.iterations; it++) {
-    for (int r = 0; __any(r < nrows); r++) {
-      if (r < nrows) {
-        T c[ROW_CORE];
-        lds.load_core(r, c);
-        const int meta = lds.meta[r * lds.lanes + lds.lane];
-        const int leg = (meta >> 5) & 3;
-        T lam = lds.lam[r * lds.lanes + lds.lane];
-        T* yp = lds.y + (leg * 3) * lds.lanes + lds.lane;
-        T y0 = yp[0], y1 = yp[lds.lanes], y2 = yp[2 * lds.lanes];
-        T lo = T(0), hi = T(1e30);
-        if (meta & 128) { hi = lds.mu[r * lds.lanes + lds.lane] * lds.lam[(meta & 31) * lds.lanes + lds.lane]; lo = -hi; }
-        T jdv = c[0] * w.a.x + c[1] * w.a.y + c[2] * w.a.z + c[3] * w.l.x + c[4] * w.l.y + c[5] * w.l.z +
-                c[6] * y0 + c[7] * y1 + c[8] * y2;
-        T sum = lam + (c[18] - jdv * c[19]);
-        sum = sum < lo ? lo : (sum > hi ? hi : sum);
-        T delta = sum - lam;
-        lds.lam[r * lds.lanes + lds.lane] = sum;
-        w.a.x += c[9] * delta; w.a.y += c[10] * delta; w.a.z += c[11] * delta;
-        w.l.x += c[12] * delta; w.l.y += c[13] * delta; w.l.z += c[14] * delta;
-        yp[0] = y0 + c[15] * delta; yp[lds.lanes] = y1 + c[16] * delta; yp[2 * lds.lanes] = y2 + c[17] * delta;
+// ---------------------------------------------------------------- phase 3: base solve + finish rows
+template <typename T, int ROBOT>
+SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const RowLds<T> lds) {
+  using RB = Robot<ROBOT>;
+  constexpr int NJ = RB::NJ, NQ = RB::NQ;
+  const T dt = pp.dt;
+  const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
+  const int nrows = nlt + 3 * nc;
+  if (mask & 0xFFF) {   // base contacts: f0 = F, no leg part
+    const M3<T> R0 = C.R0;
+    static_for<12>([&](auto pc) {
+      constexpr int p = decltype(pc)::value;
+      constexpr solorl_prim_data PR = RB::MD.prims[p];
+      if ((mask >> p) & 1) {
+        const int cidx = __popc(mask & ((1 << p) - 1));
+        const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
+        const V3<T> P = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
+        const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
+        const T Z[3] = {T(0), T(0), T(0)};
+        static_for<3>([&](auto dc) {
+          constexpr int d = decltype(dc)::value;
+          V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
+          park_row(lds, d == 0 ? sn_ : sf_ + (d - 1), SV<T>{cross(P, u), u}, Z, Z, P, C.dist[p] + pp.slop,
+                   d == 0 ? lam0 : T(0), T(PR.friction), (d == 0 ? 0 : (sn_ | 128)) | (d << 8));
+        });
       }
+    });
+  }
+  if (nrows == 0) {   // the branch-free PGS sweep touches row 0 of every lane: make it a null row
+    const T Z[3] = {T(0), T(0), T(0)};
+    park_row(lds, 0, zero6<T>(), Z, Z, mk(T(0), T(0), T(0)), T(0), T(0), T(0), 0);
+    lds.lam()[lds.lane] = T(0);
+  }
+  // base acceleration (gravity via the accelerating-frame trick), u* = u + dt*udot
+  const Sym6<T> Lam = spd_inverse(C.Ibase);
+  const SV<T> a0 = mul(Lam, C.pbase) * T(-1);
+  static_for<4>([&](auto lc) {
+    constexpr int L = decltype(lc)::value;
+#pragma unroll
+    for (int k = 0; k < NJ; k++) {
+      T qdd = C.LR[L].qdd0[k] - dot(C.LR[L].G[k], a0);
+      T v = clampv(C.ps.qd[L * NJ + k] + dt * qdd, pp.vmax);
+      C.qds[L * NJ + k] = v;
+      lds.qs()[(L * 3 + k) * lds.lanes + lds.lane] = v;
+      lds.y()[(L * 3 + k) * lds.lanes + lds.lane] = T(0);
+    }
+    if constexpr (NJ < 3) { lds.qs()[(L * 3 + 2) * lds.lanes + lds.lane] = T(0); lds.y()[(L * 3 + 2) * lds.lanes + lds.lane] = T(0); }
+  });
+  const V3<T> bw = C.ps.w, bv = C.ps.v;
+  V3<T> vdot = a0.l + cross(bw, bv); vdot.z -= pp.gravity;
+  SV<T> ub;
+  ub.a = mk(clampv(bw.x + dt * a0.a.x, pp.vmax), clampv(bw.y + dt * a0.a.y, pp.vmax), clampv(bw.z + dt * a0.a.z, pp.vmax));
+  ub.l = mk(clampv(bv.x + dt * vdot.x, pp.vmax), clampv(bv.y + dt * vdot.y, pp.vmax), clampv(bv.z + dt * vdot.z, pp.vmax));
+  C.ub = ub;
+  // finish the parked rows (W = Lam f0, diagonal, right-hand side, warm start)
+  SV<T> w = zero6<T>();
+  for (int r = 0; __any(r < nrows); r++) {
+    if (r < nrows) {
+      T c[ROW_CORE];
+      lds.load_core(r, c);
+      const int meta = lds.meta()[r * lds.lanes + lds.lane];
+      const int leg = (meta >> 5) & 3, dir = (meta >> 8) & 3;
+      const SV<T> f0{{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
+      const V3<T> P = mk(c[9], c[10], c[11]);
+      const V3<T> u = mk(dir == 1 ? T(1) : T(0), dir == 2 ? T(1) : T(0), dir == 0 ? T(1) : T(0));
+      T* yp = lds.y() + (leg * 3) * lds.lanes + lds.lane;
+      const T* qp = lds.qs() + (leg * 3) * lds.lanes + lds.lane;
+      const T rel = dot(cross(P, u), ub.a) + dot(u, ub.l) + c[6] * qp[0] + c[7] * qp[lds.lanes] + c[8] * qp[2 * lds.lanes];
+      const SV<T> W = mul(Lam, f0);
+      const T denom = dot(f0, W) + c[6] * c[15] + c[7] * c[16] + c[8] * c[17];
+      const T dinv = T(1) / denom;
+      T rhs;
+      if (meta & 128) rhs = -rel * dinv;
+      else {
+        const T pen = c[12];
+        T pos = T(0), vel = -rel;
+        if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * pp.erp * pp.inv_dt;
+        rhs = (pos + vel) * dinv;
+      }
+      const T lam0 = c[13];
+      c[9] = W.a.x; c[10] = W.a.y; c[11] = W.a.z; c[12] = W.l.x; c[13] = W.l.y; c[14] = W.l.z; c[18] = rhs; c[19] = dinv;
+      lds.store_core(r, c);
+      lds.lam()[r * lds.lanes + lds.lane] = lam0;
+      w = fma6(W, lam0, w);   // warm start: dV += M^-1 J^T lam0
+      yp[0] += c[15] * lam0; yp[lds.lanes] += c[16] * lam0; yp[2 * lds.lanes] += c[17] * lam0;
     }
   }
+  C.w = w;
+}
 
-  // ---- stage E: apply delta-velocities (clamp K5), cache impulses, semi-implicit Euler (K1)
+// ---------------------------------------------------------------- phase 4: projected Gauss-Seidel (K7)
+// Row order = LDS order: [limit rows | normals by primitive id | friction pairs by primitive id].
+// Row-index driven: in sweep step r every lane updates ITS row r, so a sweep costs the wave's
+// maximum row count (not the union of all primitives).  Software pipelined: row r+1's record,
+// impulse, friction coefficient and leg id are fetched while row r is computed; a friction row's
+// parent is found arithmetically (parent = nlim + (r - nlim - nc)/2), so there is no dependent
+// LDS chain.  Accumulators: base delta-velocity w in registers, leg delta-rates y in LDS.
+template <typename T, int ROBOT>
+SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
+  using Chunk = typename RowLds<T>::Chunk;
+  constexpr int NCH = RowLds<T>::NCH;
+  const int nlt = C.nlim_total, nc = C.nc;
+  const int nrows = nlt + 3 * nc, rfric = nlt + nc;
+  SV<T> w = C.w;
+  const int L = lds.lanes;
+  const Chunk* const corev = lds.core() + lds.lane * NCH;   // row r at corev + r*L*NCH
+  T* const lamv = lds.lam() + lds.lane;
+  T* const yv = lds.y() + lds.lane;
+  const T* const muv = lds.mu() + lds.lane;
+  const int* const metav = lds.meta() + lds.lane;
+  int wmax = nrows;   // wave-uniform maximum row count
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { int t = __shfl_xor(wmax, o); wmax = t > wmax ? t : wmax; }
+  const int last = nrows > 0 ? nrows - 1 : 0;   // lanes past their last row re-process it with delta forced to 0
+
+  struct Row { T c[ROW_CORE]; T lam, mu, lamp; int yoff; };
+  auto fetch = [&](int rr, Row& R) {     // everything of row rr except its parent impulse
+    const Chunk* p = corev + rr * (L * NCH);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      Chunk ch = p[c];
+      if constexpr (sizeof(T) == 4) { R.c[4 * c] = ch.x; R.c[4 * c + 1] = ch.y; R.c[4 * c + 2] = ch.z; R.c[4 * c + 3] = ch.w; }
+      else { R.c[2 * c] = ch.x; R.c[2 * c + 1] = ch.y; }
+    }
+    R.lam = lamv[rr * L]; R.mu = muv[rr * L];
+    R.yoff = (metav[rr * L] >> 10) * L;        // meta bits 10.. = 3*leg
+  };
+  auto parent = [&](int rr) {            // parent impulse of friction row rr (clamped: harmless for other rows)
+    int pi = nlt + ((rr - rfric) >> 1);
+    pi = pi < 0 ? 0 : pi;
+    return lamv[pi * L];
+  };
+  // update row r held in R; N receives row r+1 (prefetched before the arithmetic)
+  auto step = [&](int r, Row& R, Row& N) {
+    const int rn = r + 1 < nrows ? r + 1 : last;
+    fetch(rn, N);
+    T* yp = yv + R.yoff;
+    const T y0 = yp[0], y1 = yp[L], y2 = yp[2 * L];
+    T jdv = R.c[0] * w.a.x + R.c[1] * w.a.y + R.c[2] * w.a.z + R.c[3] * w.l.x + R.c[4] * w.l.y + R.c[5] * w.l.z;
+    jdv += R.c[6] * y0 + R.c[7] * y1 + R.c[8] * y2;
+    const bool fr = r >= rfric;
+    const T hi = fr ? R.mu * R.lamp : T(1e30);
+    const T lo = fr ? -hi : T(0);
+    T sum = R.lam + (R.c[18] - jdv * R.c[19]);
+    sum = sum < lo ? lo : (sum > hi ? hi : sum);
+    const T delta = r < nrows ? sum - R.lam : T(0);
+    if (r < nrows) lamv[r * L] = sum;    // (a clamped re-fetch of the last row holds its pre-update impulse: never store it)
+    w.a.x += R.c[9] * delta; w.a.y += R.c[10] * delta; w.a.z += R.c[11] * delta;
+    w.l.x += R.c[12] * delta; w.l.y += R.c[13] * delta; w.l.z += R.c[14] * delta;
+    yp[0] = y0 + R.c[15] * delta; yp[L] = y1 + R.c[16] * delta; yp[2 * L] = y2 + R.c[17] * delta;
+    N.lamp = parent(rn);                 // after this row's store: the parent may be this very row
+  };
+#pragma unroll 1
+  for (int it = 0; it < iterations; it++) {
+    Row A, B;
+    fetch(0, A); A.lamp = T(0);
+#pragma unroll 1
+    for (int r = 0; r < wmax; r += 2) {  // ping-pong: no register rotation
+      step(r, A, B);
+      step(r + 1, B, A);
+    }
+  }
+  C.w = w;
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) C.y[l][k] = yv[(l * 3 + k) * L];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int p = 12 + i;
+    C.lam_n[i] = ((C.mask >> p) & 1) ? lamv[(nlt + __popc(C.mask & ((1 << p) - 1))) * L] : T(0);
+  }
+}
+
+// ---------------------------------------------------------------- phase 5: apply + integrate
+// delta-velocities (clamp K5), impulse cache, semi-implicit Euler (K1)
+template <typename T, int ROBOT>
+SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const RowLds<T> lds) {
+  using RB = Robot<ROBOT>;
+  constexpr int NJ = RB::NJ;
+  const T dt = pp.dt;
+  const int mask = C.mask, nlt = C.nlim_total;
   static_for<NPRIM>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     T l = T(0);
-    if ((mask >> p) & 1) l = lds.lam[(nlim + __popc(mask & ((1 << p) - 1))) * lds.lanes + lds.lane];
+    if constexpr (p < 12) {
+      if ((mask >> p) & 1) l = lds.lam()[(nlt + __popc(mask & ((1 << p) - 1))) * lds.lanes + lds.lane];
+    } else l = C.lam_n[p - 12];
     lam_prev[(size_t)p * nstride] = l;
   });
+  const SV<T> w = C.w, ub = C.ub;
+  PhysState<T, RB::NQ> st = C.ps;
   st.w = mk(clampv(ub.a.x + w.a.x, pp.vmax), clampv(ub.a.y + w.a.y, pp.vmax), clampv(ub.a.z + w.a.z, pp.vmax));
   st.v = mk(clampv(ub.l.x + w.l.x, pp.vmax), clampv(ub.l.y + w.l.y, pp.vmax), clampv(ub.l.z + w.l.z, pp.vmax));
   static_for<4>([&](auto lc) {
     constexpr int L = decltype(lc)::value;
-    SV<T> dv = w;
-    static_for<NJ>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const JointF<T>& J = jf[L][k];
-      T z = -dot(J.U, dv) * J.Dinv;
-      if constexpr (k < NJ - 1) dv = fma6(J.S, z, dv);
-      T yk = lds.y[(L * 3 + k) * lds.lanes + lds.lane];
-      T nv = clampv(qds[L * NJ + k] + yk + z, pp.vmax);
+#pragma unroll
+    for (int k = 0; k < NJ; k++) {
+      T nv = clampv(C.qds[L * NJ + k] + C.y[L][k] - dot(C.LR[L].G[k], w), pp.vmax);
       st.qd[L * NJ + k] = nv;
       st.q[L * NJ + k] += dt * nv;
-    });
+    }
   });
   st.pos = fma3(st.v, dt, st.pos);
   {
@@ -483,7 +675,23 @@ SD int substep(PhysState<T, Robot<ROBOT>::NQ>& st, const T* tau, const PhysParam
     T inv = T(1) / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
     st.qx = nx * inv; st.qy = ny * inv; st.qz = nz * inv; st.qw = nw * inv;
   }
-  return mask;
+  C.ps = st;
+}
+
+// ---------------------------------------------------------------- one physics sub-step
+// C.ps / C.tau: state and the joint torques applied during this sub-step.  lam_prev: per-primitive
+// warm-start impulses (global memory, stride = nstride).  Returns the contact bit mask.
+template <typename T, int ROBOT>
+SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const RowLds<T>& lds) {
+  phase_detect<T, ROBOT>(C, pp);
+  phase_leg<T, ROBOT, 0>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 1>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 2>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 3>(C, pp, lam_prev, nstride, lds);
+  phase_base<T, ROBOT>(C, pp, lam_prev, nstride, lds);
+  phase_pgs<T, ROBOT>(C, pp.iterations, lds);
+  phase_integrate<T, ROBOT>(C, pp, lam_prev, nstride, lds);
+  return C.mask;
 }
 
 }  // namespace solo

@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -214,17 +215,21 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
 }
 
 // ---------------------------------------------------------------- the hot kernel
-template <typename T, int ROBOT, int EPB>
-__global__ void __launch_bounds__(EPB)
+// One env per lane, `blockDim.x` (= envs per wavefront, 1..64) lanes per workgroup.  The kernel is
+// latency/issue bound and independent per env, so for small batches the host launches MORE waves
+// with FEWER active lanes each (one wave per SIMD: 4096 envs -> 1024 waves of 4 lanes) instead of
+// 64 full waves on a 1024-SIMD chip.
+template <typename T, int ROBOT>
+__global__ void __launch_bounds__(64)
 step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
             Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
   using RB = Robot<ROBOT>;
   constexpr int NQ = RB::NQ;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
+  const int EPB = blockDim.x;
   const size_t e = (size_t)blockIdx.x * EPB + lane;
   if (e >= (size_t)N) return;
-  RowLds<T> lds; lds.carve(smem, EPB, lane);
+  RowLds<T> lds; lds.lanes = EPB; lds.lane = lane;
   Env<T, NQ> E;
   load_env(E, sf, si, L, (size_t)N, e);
 
@@ -255,13 +260,17 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
       }
   }
   E.xyprev[0] = E.ps.pos.x; E.xyprev[1] = E.ps.pos.y;
+  {
+    SubCtx<T, ROBOT> C;
+    C.ps = E.ps;
 #pragma unroll 1
-  for (int ss = 0; ss < P.frame_skip; ss++) {
-    T te[NQ];
-    const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
+    for (int ss = 0; ss < P.frame_skip; ss++) {
+      const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
 #pragma unroll
-    for (int j = 0; j < NQ; j++) te[j] = tau[j] * sc;
-    E.mask = substep<T, ROBOT>(E.ps, te, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
+      for (int j = 0; j < NQ; j++) C.tau[j] = tau[j] * sc;
+      E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
+    }
+    E.ps = C.ps;
   }
   if (P.task == SOLORL_TASK_POINTGOAL && mode == MODE_STEP) {
     T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
@@ -378,7 +387,7 @@ struct solorl_env {
   void* sf = nullptr; int* si = nullptr; void* snf = nullptr; int* sni = nullptr;
   uint64_t seed = 0; int64_t id0 = 0;
   double goal_radius = 2.0;
-  size_t smem = 0;
+  int epw = 64;   // envs per wavefront (lanes per workgroup)
 };
 
 namespace {
@@ -401,17 +410,20 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   return p;
 }
 
-template <typename T, int ROBOT, int EPB>
+template <typename T, int ROBOT>
 int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
-  auto kern = step_kernel<T, ROBOT, EPB>;
+  auto kern = step_kernel<T, ROBOT>;
+  const int EPB = N < h->epw ? N : h->epw;
+  const size_t smem = RowLds<T>::bytes(EPB);
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   int dev = h->device & 7;
   if (!attr_set[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)RowLds<T>::bytes(sizeof(T) == 8 ? 32 : 64)));
     attr_set[dev] = true;
   }
   dim3 grid((N + EPB - 1) / EPB), block(EPB);
-  hipLaunchKernelGGL(kern, grid, block, h->smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
+  hipLaunchKernelGGL(kern, grid, block, smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
                      make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -419,10 +431,10 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
 
 int dispatch_step(solorl_env* h, void* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
   const bool s12 = h->cfg.robot == SOLORL_ROBOT_SOLO12;
-  if (!h->f64) return s12 ? launch_step<float, 1, 64>(h, (float*)sf, si, N, actions, out, mode, st)
-                          : launch_step<float, 0, 64>(h, (float*)sf, si, N, actions, out, mode, st);
-  return s12 ? launch_step<double, 1, 32>(h, (double*)sf, si, N, actions, out, mode, st)
-             : launch_step<double, 0, 32>(h, (double*)sf, si, N, actions, out, mode, st);
+  if (!h->f64) return s12 ? launch_step<float, 1>(h, (float*)sf, si, N, actions, out, mode, st)
+                          : launch_step<float, 0>(h, (float*)sf, si, N, actions, out, mode, st);
+  return s12 ? launch_step<double, 1>(h, (double*)sf, si, N, actions, out, mode, st)
+             : launch_step<double, 0>(h, (double*)sf, si, N, actions, out, mode, st);
 }
 
 template <typename T> int build_snapshots_t(solorl_env* h) {
@@ -499,7 +511,18 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   h->L = make_layout(h->n, h->D, cfg->num_history_stack);
   h->M = cfg->settle_max - cfg->settle_min + 1;
   h->goal_radius = cfg->goal_radius;
-  h->smem = h->f64 ? RowLds<double>::bytes(32) : RowLds<float>::bytes(64);
+  {
+    // envs per wavefront: fill the chip's 256 CUs x 4 SIMDs with one wave each before packing lanes
+    int dev_cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
+    const int target_waves = dev_cus * 4;
+    int epw = 1;
+    while (epw < 64 && (num_envs + epw - 1) / epw > target_waves) epw *= 2;
+    if (const char* ev = getenv("SOLORL_ENVS_PER_WAVE")) { int v = atoi(ev); if (v >= 1 && v <= 64) epw = v; }
+    if (h->f64 && epw > 32) epw = 32;
+    h->epw = epw;
+  }
   auto cleanup = [&](int code) { solorl_destroy(h); return code; };
   if (hipMalloc(&h->sf, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state"));
   if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));

@@ -11,6 +11,7 @@
 #else
 #include <hip/hip_runtime.h>
 #define SD __device__ __forceinline__
+#define SNI __device__ __noinline__
 #endif
 
 namespace solo {

@@ -5,10 +5,12 @@
 #include <cstddef>
 #include <type_traits>
 #define SD inline
+#define SNI static __attribute__((noinline))
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 inline double2 make_double2(double x, double y) { return {x, y}; }
 inline int __popc(int x) { return __builtin_popcount((unsigned)x); }
 inline bool __any(bool x) { return x; }
+inline int __shfl_xor(int v, int) { return v; }
 using std::sqrt; using std::floor; using std::fabs; using std::atan2; using std::asin;

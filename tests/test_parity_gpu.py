@@ -29,6 +29,16 @@ def make(cfg, N, seed=1, off=0):
     return SoloVecEnv(cfg, N, device="cuda:0", seed=seed, env_id_offset=off), Oracle(cfg, N, seed=seed, env_id_offset=off)
 
 
+def obs_diff(a, b, D):
+    """|a-b| with the euler entries compared modulo the wrap of the reference's (euler % 2)/2 quirk
+    (solo.py:206): an angle of -1e-9 reads 0.9999999995, +1e-9 reads 0 -- same pose."""
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    for base in range(0, d.shape[-1], D):
+        e = d[..., base + 1:base + 4]
+        d[..., base + 1:base + 4] = np.minimum(e, np.abs(1.0 - e))
+    return d
+
+
 def cfg_for(robot, task, control=CONTROL_TORQUE, **kw):
     c = default_config(robot, task); c.num_history_stack = 1; c.control = control
     for k, v in kw.items():
@@ -51,7 +61,7 @@ def test_reset_matches_oracle(gpu_device, robot, task):
     env, orc = make(c, 256, seed=7)
     og = env.reset().cpu().numpy().astype(np.float64); oo = orc.reset()
     assert og.shape == oo.shape == (256, c.obs_dim)
-    assert np.abs(og - oo).max() < 2e-3
+    assert obs_diff(og, oo, c.state_dim).max() < 2e-3
     for i in (0, 17, 255):
         sg, so = env.get_state(i), orc.get_state(i)
         assert sg.rng_counter == so.rng_counter and sg.timestep == 0 and sg.contact_mask == so.contact_mask
@@ -90,7 +100,7 @@ def test_step_matches_oracle_resynced(gpu_device, robot, task, control):
             dq_all.append(np.abs(np.array(sg.q)[:n] - np.array(so.q)[:n]).max())
             mask_mismatch += sg.contact_mask != so.contact_mask
         ok = (done == 0) & (odone == 0)
-        dr_all += list(np.abs(rew - orew)[ok]); dobs_all += list(np.abs(obs - oobs)[ok].max(axis=1))
+        dr_all += list(np.abs(rew - orew)[ok]); dobs_all += list(obs_diff(obs, oobs, c.state_dim)[ok].max(axis=1))
         t_info = infos.tensors
         assert np.array_equal(t_info["episode_length"].cpu().numpy()[ok], oinfo["episode_length"][ok])
     dq_all = np.array(dq_all)
@@ -141,7 +151,7 @@ def test_termination_and_autoreset_semantics(gpu_device):
     assert rew.shape == (64, 1) and done.dtype == torch.float32 and obs.dtype == torch.float32
     s = env.get_state(0)
     assert s.timestep == 0 and all(v == 0 for v in s.dr)                      # obs/state are post-reset
-    assert np.abs(obs.cpu().numpy() - oobs).max() < 2e-3
+    assert obs_diff(obs.cpu().numpy(), oobs, c.state_dim).max() < 2e-3
     # fall -> -10, not timeout, not success
     c = cfg_for(ROBOT_SOLO12, TASK_WALK)
     env, _ = make(c, 4)
