@@ -74,7 +74,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char solo_smem[];
 template <typename T> struct RowLds {
   static constexpr int PER = 16 / sizeof(T);            // values per 16-byte chunk (4 float / 2 double)
   static constexpr int NCH = ROW_CORE / PER;            // 5 / 10
+  static constexpr int YSTRIDE = 13;                    // per-lane y record: 12 values + 1 pad (odd stride: conflict-free)
   using Chunk = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
+  struct Aux { T mu, lam, yoff, meta; };                // per row and lane: friction coefficient, impulse,
+                                                        // 3*leg (as T), meta bits (as T)
+  // meta bits: 0-4 parent row, 5-6 leg, 7 is_friction, 8-9 direction (0 z, 1 x, 2 y, 3 joint)
   int lanes, lane;
 #ifdef SOLO_HOST_SHIM
   unsigned char* base;
@@ -83,12 +87,10 @@ template <typename T> struct RowLds {
   SD unsigned char* smem() const { return solo_smem; }
 #endif
   SD Chunk* core() const { return reinterpret_cast<Chunk*>(smem()); }   // [MAX_ROWS][lanes][NCH]
-  SD T* mu() const { return reinterpret_cast<T*>(smem() + (size_t)MAX_ROWS * lanes * ROW_CORE * sizeof(T)); }
-  SD T* lam() const { return mu() + MAX_ROWS * lanes; }
-  SD T* y() const { return lam() + MAX_ROWS * lanes; }     // [12][lanes] leg delta-rates, base fixed
-  SD T* qs() const { return y() + 12 * lanes; }            // [12][lanes] unconstrained joint rates u*
-  SD int* meta() const { return reinterpret_cast<int*>(qs() + 12 * lanes); }
-  // meta bits: 0-4 parent row, 5-6 leg, 7 is_friction, 8-9 direction (0 z, 1 x, 2 y, 3 joint)
+  SD Aux* aux() const { return reinterpret_cast<Aux*>(smem() + (size_t)MAX_ROWS * lanes * ROW_CORE * sizeof(T)); }  // [MAX_ROWS][lanes]
+  SD T* y() const { return reinterpret_cast<T*>(aux() + MAX_ROWS * lanes); }   // [lanes][YSTRIDE] leg delta-rates, base fixed
+  SD Aux& A(int r) const { return aux()[r * lanes + lane]; }
+  SD T* ylane() const { return y() + lane * YSTRIDE; }
 
   SD void store_core(int r, const T (&v)[ROW_CORE]) const {
     Chunk* p = core() + (r * lanes + lane) * NCH;
@@ -110,8 +112,7 @@ template <typename T> struct RowLds {
     }
   }
   static constexpr size_t bytes(int lanes_) {
-    return (size_t)MAX_ROWS * lanes_ * ROW_CORE * sizeof(T) + (size_t)MAX_ROWS * lanes_ * (2 * sizeof(T) + sizeof(int)) +
-           (size_t)24 * lanes_ * sizeof(T);
+    return (size_t)MAX_ROWS * lanes_ * (ROW_CORE + 4) * sizeof(T) + (size_t)lanes_ * YSTRIDE * sizeof(T);
   }
 };
 
@@ -242,8 +243,9 @@ SD void park_row(const RowLds<T>& lds, int slot, SV<T> f0, const T (&JL)[3], con
   core[9] = P.x; core[10] = P.y; core[11] = P.z; core[12] = pen; core[13] = lam0; core[14] = T(0);
   core[15] = Y[0]; core[16] = Y[1]; core[17] = Y[2]; core[18] = T(0); core[19] = T(0);
   lds.store_core(slot, core);
-  lds.mu()[slot * lds.lanes + lds.lane] = mu;
-  lds.meta()[slot * lds.lanes + lds.lane] = meta;
+  typename RowLds<T>::Aux a;
+  a.mu = mu; a.lam = T(0); a.yoff = T(3 * ((meta >> 5) & 3)); a.meta = T(meta);
+  lds.A(slot) = a;
 }
 
 // ---------------------------------------------------------------- phase 1: collision detection
@@ -419,7 +421,7 @@ SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
         T sg = side == 0 ? T(1) : T(-1);
         T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
         JL[k] = sg;
-        park_row(lds, nlim, LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8) | ((3 * L) << 10));
+        park_row(lds, nlim, LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
         nlim++;
       }
     }
@@ -452,7 +454,7 @@ SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
 #pragma unroll
         for (int r = 0; r < 3; r++) Y[r] = Minv[r][0] * JL[0] + Minv[r][1] * JL[1] + Minv[r][2] * JL[2];
         park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0), T(PR.friction),
-                 (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8) | ((3 * L) << 10));
+                 (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8));
       });
     }
   });
@@ -489,7 +491,6 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
   if (nrows == 0) {   // the branch-free PGS sweep touches row 0 of every lane: make it a null row
     const T Z[3] = {T(0), T(0), T(0)};
     park_row(lds, 0, zero6<T>(), Z, Z, mk(T(0), T(0), T(0)), T(0), T(0), T(0), 0);
-    lds.lam()[lds.lane] = T(0);
   }
   // base acceleration (gravity via the accelerating-frame trick), u* = u + dt*udot
   const Sym6<T> Lam = spd_inverse(C.Ibase);
@@ -501,11 +502,16 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
       T qdd = C.LR[L].qdd0[k] - dot(C.LR[L].G[k], a0);
       T v = clampv(C.ps.qd[L * NJ + k] + dt * qdd, pp.vmax);
       C.qds[L * NJ + k] = v;
-      lds.qs()[(L * 3 + k) * lds.lanes + lds.lane] = v;
-      lds.y()[(L * 3 + k) * lds.lanes + lds.lane] = T(0);
     }
-    if constexpr (NJ < 3) { lds.qs()[(L * 3 + 2) * lds.lanes + lds.lane] = T(0); lds.y()[(L * 3 + 2) * lds.lanes + lds.lane] = T(0); }
   });
+  T qsl[4][3];   // unconstrained joint rates per leg, padded to 3
+#pragma unroll
+  for (int L = 0; L < 4; L++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) qsl[L][k] = k < NJ ? C.qds[L * NJ + k] : T(0);
+  T* const yl = lds.ylane();
+#pragma unroll
+  for (int k = 0; k < 12; k++) yl[k] = T(0);
   const V3<T> bw = C.ps.w, bv = C.ps.v;
   V3<T> vdot = a0.l + cross(bw, bv); vdot.z -= pp.gravity;
   SV<T> ub;
@@ -518,14 +524,16 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
     if (r < nrows) {
       T c[ROW_CORE];
       lds.load_core(r, c);
-      const int meta = lds.meta()[r * lds.lanes + lds.lane];
+      const int meta = (int)lds.A(r).meta;
       const int leg = (meta >> 5) & 3, dir = (meta >> 8) & 3;
       const SV<T> f0{{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
       const V3<T> P = mk(c[9], c[10], c[11]);
       const V3<T> u = mk(dir == 1 ? T(1) : T(0), dir == 2 ? T(1) : T(0), dir == 0 ? T(1) : T(0));
-      T* yp = lds.y() + (leg * 3) * lds.lanes + lds.lane;
-      const T* qp = lds.qs() + (leg * 3) * lds.lanes + lds.lane;
-      const T rel = dot(cross(P, u), ub.a) + dot(u, ub.l) + c[6] * qp[0] + c[7] * qp[lds.lanes] + c[8] * qp[2 * lds.lanes];
+      T* yp = yl + leg * 3;
+      const T q0 = leg == 0 ? qsl[0][0] : leg == 1 ? qsl[1][0] : leg == 2 ? qsl[2][0] : qsl[3][0];
+      const T q1 = leg == 0 ? qsl[0][1] : leg == 1 ? qsl[1][1] : leg == 2 ? qsl[2][1] : qsl[3][1];
+      const T q2 = leg == 0 ? qsl[0][2] : leg == 1 ? qsl[1][2] : leg == 2 ? qsl[2][2] : qsl[3][2];
+      const T rel = dot(cross(P, u), ub.a) + dot(u, ub.l) + c[6] * q0 + c[7] * q1 + c[8] * q2;
       const SV<T> W = mul(Lam, f0);
       const T denom = dot(f0, W) + c[6] * c[15] + c[7] * c[16] + c[8] * c[17];
       const T dinv = T(1) / denom;
@@ -540,9 +548,9 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
       const T lam0 = c[13];
       c[9] = W.a.x; c[10] = W.a.y; c[11] = W.a.z; c[12] = W.l.x; c[13] = W.l.y; c[14] = W.l.z; c[18] = rhs; c[19] = dinv;
       lds.store_core(r, c);
-      lds.lam()[r * lds.lanes + lds.lane] = lam0;
+      lds.A(r).lam = lam0;
       w = fma6(W, lam0, w);   // warm start: dV += M^-1 J^T lam0
-      yp[0] += c[15] * lam0; yp[lds.lanes] += c[16] * lam0; yp[2 * lds.lanes] += c[17] * lam0;
+      yp[0] += c[15] * lam0; yp[1] += c[16] * lam0; yp[2] += c[17] * lam0;
     }
   }
   C.w = w;
@@ -558,62 +566,69 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
 template <typename T, int ROBOT>
 SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
   using Chunk = typename RowLds<T>::Chunk;
+  using Aux = typename RowLds<T>::Aux;
   constexpr int NCH = RowLds<T>::NCH;
   const int nlt = C.nlim_total, nc = C.nc;
   const int nrows = nlt + 3 * nc, rfric = nlt + nc;
   SV<T> w = C.w;
   const int L = lds.lanes;
   const Chunk* const corev = lds.core() + lds.lane * NCH;   // row r at corev + r*L*NCH
-  T* const lamv = lds.lam() + lds.lane;
-  T* const yv = lds.y() + lds.lane;
-  const T* const muv = lds.mu() + lds.lane;
-  const int* const metav = lds.meta() + lds.lane;
+  Aux* const auxv = lds.aux() + lds.lane;                    // row r at auxv + r*L
+  T* const yl = lds.ylane();
   int wmax = nrows;   // wave-uniform maximum row count
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { int t = __shfl_xor(wmax, o); wmax = t > wmax ? t : wmax; }
   const int last = nrows > 0 ? nrows - 1 : 0;   // lanes past their last row re-process it with delta forced to 0
 
-  struct Row { T c[ROW_CORE]; T lam, mu, lamp; int yoff; };
-  auto fetch = [&](int rr, Row& R) {     // everything of row rr except its parent impulse
-    const Chunk* p = corev + rr * (L * NCH);
+  // The kernel's duration is the SLOWEST wave, i.e. the sequential sweep of the heaviest env, so the
+  // loop is organised for LATENCY: row r+1's record, aux and leg accumulators are fetched while row
+  // r is computed; if r+1 works on the same leg (or has row r as friction parent) the freshly
+  // computed register values are forwarded instead of waiting for an LDS store->load round trip.
+  struct Row { T c[ROW_CORE]; T mu, lam, lamp, y0, y1, y2; int yoff, par; };
+  auto fetch = [&](int rr, Row& R) {
+    const Chunk* p = corev + __mul24(rr, L * NCH);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       Chunk ch = p[c];
       if constexpr (sizeof(T) == 4) { R.c[4 * c] = ch.x; R.c[4 * c + 1] = ch.y; R.c[4 * c + 2] = ch.z; R.c[4 * c + 3] = ch.w; }
       else { R.c[2 * c] = ch.x; R.c[2 * c + 1] = ch.y; }
     }
-    R.lam = lamv[rr * L]; R.mu = muv[rr * L];
-    R.yoff = (metav[rr * L] >> 10) * L;        // meta bits 10.. = 3*leg
+    const Aux a = auxv[__mul24(rr, L)];
+    R.mu = a.mu; R.lam = a.lam; R.yoff = (int)a.yoff;
+    int pi = nlt + ((rr - rfric) >> 1);                  // friction parent (clamped: harmless for other rows)
+    R.par = pi < 0 ? 0 : pi;
+    R.lamp = auxv[__mul24(R.par, L)].lam;
+    R.y0 = yl[R.yoff]; R.y1 = yl[R.yoff + 1]; R.y2 = yl[R.yoff + 2];
   };
-  auto parent = [&](int rr) {            // parent impulse of friction row rr (clamped: harmless for other rows)
-    int pi = nlt + ((rr - rfric) >> 1);
-    pi = pi < 0 ? 0 : pi;
-    return lamv[pi * L];
-  };
-  // update row r held in R; N receives row r+1 (prefetched before the arithmetic)
+  // update row r (in R); N receives row r+1, fetched before the arithmetic, patched after it
   auto step = [&](int r, Row& R, Row& N) {
     const int rn = r + 1 < nrows ? r + 1 : last;
     fetch(rn, N);
-    T* yp = yv + R.yoff;
-    const T y0 = yp[0], y1 = yp[L], y2 = yp[2 * L];
     T jdv = R.c[0] * w.a.x + R.c[1] * w.a.y + R.c[2] * w.a.z + R.c[3] * w.l.x + R.c[4] * w.l.y + R.c[5] * w.l.z;
-    jdv += R.c[6] * y0 + R.c[7] * y1 + R.c[8] * y2;
-    const bool fr = r >= rfric;
+    jdv += R.c[6] * R.y0 + R.c[7] * R.y1 + R.c[8] * R.y2;
+    const bool fr = r >= rfric, live = r < nrows;
     const T hi = fr ? R.mu * R.lamp : T(1e30);
     const T lo = fr ? -hi : T(0);
     T sum = R.lam + (R.c[18] - jdv * R.c[19]);
     sum = sum < lo ? lo : (sum > hi ? hi : sum);
-    const T delta = r < nrows ? sum - R.lam : T(0);
-    if (r < nrows) lamv[r * L] = sum;    // (a clamped re-fetch of the last row holds its pre-update impulse: never store it)
+    sum = live ? sum : R.lam;
+    const T delta = sum - R.lam;
     w.a.x += R.c[9] * delta; w.a.y += R.c[10] * delta; w.a.z += R.c[11] * delta;
     w.l.x += R.c[12] * delta; w.l.y += R.c[13] * delta; w.l.z += R.c[14] * delta;
-    yp[0] = y0 + R.c[15] * delta; yp[L] = y1 + R.c[16] * delta; yp[2 * L] = y2 + R.c[17] * delta;
-    N.lamp = parent(rn);                 // after this row's store: the parent may be this very row
+    const T y0 = R.y0 + R.c[15] * delta, y1 = R.y1 + R.c[16] * delta, y2 = R.y2 + R.c[17] * delta;
+    const int rw = live ? r : last;
+    auxv[__mul24(rw, L)].lam = sum;                      // (dead lanes rewrite their last row's own value)
+    yl[R.yoff] = y0; yl[R.yoff + 1] = y1; yl[R.yoff + 2] = y2;
+    // forward what the prefetch could not have seen yet
+    const bool samey = N.yoff == R.yoff;
+    N.y0 = samey ? y0 : N.y0; N.y1 = samey ? y1 : N.y1; N.y2 = samey ? y2 : N.y2;
+    N.lamp = N.par == rw ? sum : N.lamp;
+    N.lam = rn == rw ? sum : N.lam;
   };
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
     Row A, B;
-    fetch(0, A); A.lamp = T(0);
+    fetch(0, A);
 #pragma unroll 1
     for (int r = 0; r < wmax; r += 2) {  // ping-pong: no register rotation
       step(r, A, B);
@@ -624,11 +639,11 @@ SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
 #pragma unroll
   for (int l = 0; l < 4; l++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) C.y[l][k] = yv[(l * 3 + k) * L];
+    for (int k = 0; k < 3; k++) C.y[l][k] = yl[l * 3 + k];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int p = 12 + i;
-    C.lam_n[i] = ((C.mask >> p) & 1) ? lamv[(nlt + __popc(C.mask & ((1 << p) - 1))) * L] : T(0);
+    C.lam_n[i] = ((C.mask >> p) & 1) ? auxv[(nlt + __popc(C.mask & ((1 << p) - 1))) * L].lam : T(0);
   }
 }
 
@@ -644,7 +659,7 @@ SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_pr
     constexpr int p = decltype(pc)::value;
     T l = T(0);
     if constexpr (p < 12) {
-      if ((mask >> p) & 1) l = lds.lam()[(nlt + __popc(mask & ((1 << p) - 1))) * lds.lanes + lds.lane];
+      if ((mask >> p) & 1) l = lds.A(nlt + __popc(mask & ((1 << p) - 1))).lam;
     } else l = C.lam_n[p - 12];
     lam_prev[(size_t)p * nstride] = l;
   });

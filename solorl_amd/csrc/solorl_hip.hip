@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -41,7 +42,7 @@ struct Layout {
   int n, D, H, NF;
   int pos, quat, v, w, q, qd, lam, hist, goal, pot, prog, goals, egoals, dr, xyprev;
 };
-enum { I_TIMESTEP = 0, I_MASK = 1, I_RNG = 2, I_NEEDRESET = 3, NI = 4 };
+enum { I_TIMESTEP = 0, I_MASK = 1, I_RNG = 2, I_NEEDRESET = 3, I_ENVID = 4, NI = 5 };   // I_ENVID: slot -> env id
 
 Layout make_layout(int n, int D, int H) {
   Layout L; int o = 0;
@@ -165,10 +166,10 @@ SD void sample_goal(Env<T, NQ>& E, const EnvParams& P, long long gid) {   // sol
 
 // SoloBaseEnv.reset (baseEnv.py:70-82) in O(1): load the pre-simulated post-settle state.
 template <typename T, int ROBOT>
-SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L, size_t N, size_t e, const T* snf,
+SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L, size_t N, size_t e, size_t env, const T* snf,
                             const int* sni, int M, const EnvParams& P) {
   constexpr int NQ = Robot<ROBOT>::NQ;
-  const long long gid = P.id0 + (long long)e;
+  const long long gid = P.id0 + (long long)env;
   int rng = E.rng;
   T g0 = E.goal[0], g1 = E.goal[1];
   Env<T, NQ> S;
@@ -200,11 +201,11 @@ SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L,
 }
 
 template <typename T, int ROBOT>
-SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& L, size_t N, size_t e, int task, float* obs) {
+SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& L, size_t N, size_t e, size_t env, int task, float* obs) {
   T cs[DMAX];
   current_state<T, ROBOT>(E, task, cs);
   const int O = L.D * (1 + L.H);
-  float* o = obs + e * (size_t)O;
+  float* o = obs + env * (size_t)O;
   // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older]
 #pragma unroll
   for (int d = 0; d < DMAX; d++)
@@ -230,6 +231,7 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
   const size_t e = (size_t)blockIdx.x * EPB + lane;
   if (e >= (size_t)N) return;
   RowLds<T> lds; lds.lanes = EPB; lds.lane = lane;
+  const size_t env = (size_t)si[(size_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
   Env<T, NQ> E;
   load_env(E, sf, si, L, (size_t)N, e);
 
@@ -237,7 +239,7 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
   T tau[NQ], asq = T(0);
 #pragma unroll
   for (int j = 0; j < NQ; j++) {
-    T a = mode == MODE_STEP ? (T)actions[e * NQ + j] : T(0);
+    T a = mode == MODE_STEP ? (T)actions[env * NQ + j] : T(0);
     asq += a * a;
     T c = a < T(-1) ? T(-1) : (a > T(1) ? T(1) : a);
     if (P.control == SOLORL_CONTROL_TORQUE) tau[j] = c * T(P.max_torque);
@@ -276,7 +278,7 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
     T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
     T np = sqrt(dx * dx + dy * dy);
     E.prog = -(np - E.pot); E.pot = np;
-    if (np < T(0.5)) { E.goals += T(1); sample_goal(E, P, P.id0 + (long long)e); }
+    if (np < T(0.5)) { E.goals += T(1); sample_goal(E, P, P.id0 + (long long)env); }
   }
   if (mode == MODE_SETTLE) { store_env(E, sf, si, L, (size_t)N, e); return; }
   E.timestep += 1;
@@ -315,23 +317,23 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
     if (su) { if (P.task == SOLORL_TASK_POINTGOAL) reward = T(0.1) * T(P.episode_length - E.timestep); }
     else if (!to) reward = T(-10);
   }
-  out.rew[e] = (float)reward;
-  out.done[e] = (unsigned char)done;
-  if (out.timeout) out.timeout[e] = (unsigned char)to;
-  if (out.success) out.success[e] = (unsigned char)su;
-  if (out.nan_reset) out.nan_reset[e] = (unsigned char)nanr;
-  if (out.ep_len) out.ep_len[e] = E.timestep;
-  if (out.ep_rew) out.ep_rew[e] = (float)reward;
-  if (out.goals) out.goals[e] = (float)E.egoals;
-  if (out.dr0) out.dr0[e] = (float)E.dr[0];
-  if (out.dr1) out.dr1[e] = (float)E.dr[1];
-  if (out.dr2) out.dr2[e] = (float)E.dr[2];
-  if (out.dr3) out.dr3[e] = (float)E.dr[3];
-  if (out.dr4) out.dr4[e] = (float)E.dr[4];
+  out.rew[env] = (float)reward;
+  out.done[env] = (unsigned char)done;
+  if (out.timeout) out.timeout[env] = (unsigned char)to;
+  if (out.success) out.success[env] = (unsigned char)su;
+  if (out.nan_reset) out.nan_reset[env] = (unsigned char)nanr;
+  if (out.ep_len) out.ep_len[env] = E.timestep;
+  if (out.ep_rew) out.ep_rew[env] = (float)reward;
+  if (out.goals) out.goals[env] = (float)E.egoals;
+  if (out.dr0) out.dr0[env] = (float)E.dr[0];
+  if (out.dr1) out.dr1[env] = (float)E.dr[1];
+  if (out.dr2) out.dr2[env] = (float)E.dr[2];
+  if (out.dr3) out.dr3[env] = (float)E.dr[3];
+  if (out.dr4) out.dr4[env] = (float)E.dr[4];
 
   // ---- auto-reset (agents/ppo/envs.py:39) and observation
-  if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, snf, sni, M, P);
-  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, P.task, out.obs);
+  if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, env, snf, sni, M, P);
+  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, env, P.task, out.obs);
   store_env(E, sf, si, L, (size_t)N, e);
 }
 
@@ -341,8 +343,9 @@ __global__ void reset_kernel(T* sf, int* si, const T* snf, const int* sni, int M
   if (e >= (size_t)N) return;
   Env<T, Robot<ROBOT>::NQ> E;
   load_env(E, sf, si, L, (size_t)N, e);
-  reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, snf, sni, M, P);
-  if (obs) write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, P.task, obs);
+  const size_t env = (size_t)si[(size_t)I_ENVID * N + e];
+  reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, env, snf, sni, M, P);
+  if (obs) write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, env, P.task, obs);
   store_env(E, sf, si, L, (size_t)N, e);
   si[(size_t)I_NEEDRESET * N + e] = 0;
 }
@@ -353,7 +356,7 @@ __global__ void obs_kernel(const T* sf, const int* si, Layout L, int N, int task
   if (e >= (size_t)N) return;
   Env<T, Robot<ROBOT>::NQ> E;
   load_env(E, sf, si, L, (size_t)N, e);
-  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, task, obs);
+  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, (size_t)si[(size_t)I_ENVID * N + e], task, obs);
 }
 
 // initial pose of SoloBase.robot_specific_reset (solo.py:291-296) for every env of a buffer
@@ -366,6 +369,7 @@ __global__ void init_pose_kernel(T* sf, int* si, Layout L, int N) {
   sf[(size_t)(L.quat + 3) * N + e] = T(1);
   for (int k = 0; k < NI; k++) si[(size_t)k * N + e] = 0;
   si[(size_t)I_NEEDRESET * N + e] = 1;
+  si[(size_t)I_ENVID * N + e] = (int)e;
 }
 
 template <typename T>
@@ -373,6 +377,53 @@ __global__ void copy_env_kernel(const T* sf, const int* si, int N, int src, T* d
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f < NF) df[(size_t)f * M + dst] = sf[(size_t)f * N + src];
   if (f < NI) di[(size_t)f * M + dst] = si[(size_t)f * N + src];
+}
+
+// ---- contact-count sorting (divergence control for the PGS sweep)
+// A PGS sweep costs a wave the MAXIMUM row count over its lanes.  Under a random policy the mean is
+// ~4 rows but the maximum over 64 arbitrary envs ~16, so the state is kept physically sorted by the
+// last contact count: a stable counting sort (9 buckets, one workgroup) yields perm[dst] = src and a
+// gather kernel moves every state field (coalesced writes).  Lanes are independent, so the
+// permutation never changes results -- only which envs share a wavefront.
+__global__ void __launch_bounds__(1024) sort_perm_kernel(const int* __restrict__ si, int N, int* __restrict__ perm) {
+  __shared__ int cnt[1024][9];
+  __shared__ int base[9];
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int chunk = (N + nt - 1) / nt, lo = t * chunk, hi = lo + chunk < N ? lo + chunk : N;
+  int c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = lo; i < hi; i++) { int k = __popc(si[(size_t)I_MASK * N + i]); k = k > 8 ? 8 : k; c[k]++; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) cnt[t][k] = c[k];
+  __syncthreads();
+  if (t < 9) {   // exclusive scan over threads for bucket t (serial: 1024 adds, negligible)
+    int run = 0;
+    for (int j = 0; j < nt; j++) { int v = cnt[j][t]; cnt[j][t] = run; run += v; }
+    base[t] = run;
+  }
+  __syncthreads();
+  if (t == 0) { int run = 0; for (int k = 0; k < 9; k++) { int v = base[k]; base[k] = run; run += v; } }
+  __syncthreads();
+  int off[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) off[k] = base[k] + cnt[t][k];
+  for (int i = lo; i < hi; i++) {
+    int k = __popc(si[(size_t)I_MASK * N + i]); k = k > 8 ? 8 : k;
+    int d = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) if (q == k) d = off[q]++;
+    perm[d] = i;
+  }
+}
+
+template <typename T>
+__global__ void gather_state_kernel(const T* __restrict__ sf, const int* __restrict__ si, const int* __restrict__ perm, int N,
+                                    int NF, T* __restrict__ df, int* __restrict__ di) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const int src = perm[j];
+  const int f = blockIdx.y;
+  if (f < NF) df[(size_t)f * N + j] = sf[(size_t)f * N + src];
+  else di[(size_t)(f - NF) * N + j] = si[(size_t)(f - NF) * N + src];
 }
 
 }  // namespace
@@ -385,9 +436,12 @@ struct solorl_env {
   size_t tsize = 4;
   Layout L;
   void* sf = nullptr; int* si = nullptr; void* snf = nullptr; int* sni = nullptr;
+  void* sf2 = nullptr; int* si2 = nullptr; int* perm = nullptr;   // double buffer + permutation for contact-count sorting
+  bool sort = true;
   uint64_t seed = 0; int64_t id0 = 0;
   double goal_radius = 2.0;
   int epw = 64;   // envs per wavefront (lanes per workgroup)
+  bool spread = true;
 };
 
 namespace {
@@ -414,7 +468,10 @@ template <typename T, int ROBOT>
 int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
   auto kern = step_kernel<T, ROBOT>;
   const int EPB = N < h->epw ? N : h->epw;
-  const size_t smem = RowLds<T>::bytes(EPB);
+  // small workgroups would be packed several to a CU (sharing its LDS pipe and issue slots) while other
+  // CUs idle; asking for (almost) the whole LDS forces one workgroup per CU.
+  size_t smem = RowLds<T>::bytes(EPB);
+  if (h->spread && (N + EPB - 1) / EPB <= 256) smem = RowLds<T>::bytes(sizeof(T) == 8 ? 32 : 64);
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   int dev = h->device & 7;
   if (!attr_set[dev]) {
@@ -512,15 +569,13 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   h->M = cfg->settle_max - cfg->settle_min + 1;
   h->goal_radius = cfg->goal_radius;
   {
-    // envs per wavefront: fill the chip's 256 CUs x 4 SIMDs with one wave each before packing lanes
-    int dev_cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
-    const int target_waves = dev_cus * 4;
-    int epw = 1;
-    while (epw < 64 && (num_envs + epw - 1) / epw > target_waves) epw *= 2;
+    // envs per wavefront.  Measured on MI355X (profiles/r01_notes.md): narrower waves do NOT help -- the
+    // kernel's duration is the sequential PGS sweep of the heaviest env, which a narrower wave
+    // still has to run, while more waves contend for the LDS/TA pipes -- so waves are kept full.
+    int epw = 64;
     if (const char* ev = getenv("SOLORL_ENVS_PER_WAVE")) { int v = atoi(ev); if (v >= 1 && v <= 64) epw = v; }
     if (h->f64 && epw > 32) epw = 32;
+    if (const char* ev = getenv("SOLORL_SPREAD")) h->spread = atoi(ev) != 0;
     h->epw = epw;
   }
   auto cleanup = [&](int code) { solorl_destroy(h); return code; };
@@ -528,6 +583,13 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
   if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
   if (hipMalloc(&h->sni, sizeof(int) * NI * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
+  h->sort = num_envs >= 256;
+  if (const char* ev = getenv("SOLORL_SORT")) h->sort = atoi(ev) != 0 && num_envs >= 2;
+  if (h->sort) {
+    if (hipMalloc(&h->sf2, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state2"));
+    if (hipMalloc(&h->si2, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate2"));
+    if (hipMalloc(&h->perm, sizeof(int) * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc perm"));
+  }
   dim3 g((num_envs + 255) / 256), b(256);
   if (h->f64) hipLaunchKernelGGL(init_pose_kernel<double>, g, b, 0, 0, (double*)h->sf, h->si, h->L, num_envs);
   else hipLaunchKernelGGL(init_pose_kernel<float>, g, b, 0, 0, (float*)h->sf, h->si, h->L, num_envs);
@@ -545,6 +607,9 @@ int solorl_destroy(solorl_env* h) {
   if (h->si) hipFree(h->si);
   if (h->snf) hipFree(h->snf);
   if (h->sni) hipFree(h->sni);
+  if (h->sf2) hipFree(h->sf2);
+  if (h->si2) hipFree(h->si2);
+  if (h->perm) hipFree(h->perm);
   delete h;
   return 0;
 }
@@ -587,6 +652,15 @@ int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* rewa
     o.ep_rew = info->episode_reward; o.goals = info->goals_reached; o.dr0 = info->dr_stand; o.dr1 = info->dr_joint_pose;
     o.dr2 = info->dr_torque; o.dr3 = info->dr_balance; o.dr4 = info->dr_progress;
   }
+  if (h->sort) {   // re-sort the state by last contact count (stable), into the spare buffer
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sort_perm_kernel, dim3(1), dim3(1024), 0, st, (const int*)h->si, h->N, h->perm);
+    dim3 g((h->N + 255) / 256, h->L.NF + NI), b(256);
+    if (h->f64) hipLaunchKernelGGL(gather_state_kernel<double>, g, b, 0, st, (const double*)h->sf, (const int*)h->si, (const int*)h->perm, h->N, h->L.NF, (double*)h->sf2, h->si2);
+    else hipLaunchKernelGGL(gather_state_kernel<float>, g, b, 0, st, (const float*)h->sf, (const int*)h->si, (const int*)h->perm, h->N, h->L.NF, (float*)h->sf2, h->si2);
+    HIP_TRY(hipGetLastError());
+    std::swap(h->sf, h->sf2); std::swap(h->si, h->si2);
+  }
   return dispatch_step(h, h->sf, h->si, h->N, actions, o, MODE_STEP, (hipStream_t)stream);
 }
 
@@ -612,10 +686,20 @@ int solorl_increment_curriculum(solorl_env* h, double value) {
   return 0;
 }
 
+static int find_slot(solorl_env* h, int env, int* slot) {
+  // the state is kept sorted by contact count: look the env up in the slot -> env-id map
+  if (!h->sort) { *slot = env; return 0; }
+  std::vector<int> ids(h->N);
+  HIP_TRY(hipMemcpy(ids.data(), h->si + (size_t)I_ENVID * h->N, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost));
+  for (int s = 0; s < h->N; s++) if (ids[s] == env) { *slot = s; return 0; }
+  return fail(SOLORL_ERR_INVALID, "env id not found in slot map");
+}
+
 int solorl_get_state(solorl_env* h, int i, solorl_env_state* out) {
   if (!h || !out || i < 0 || i >= h->N) return fail(SOLORL_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
+  { int rc_ = find_slot(h, i, &i); if (rc_) return rc_; }
   std::vector<double> f(h->L.NF);
   int iv[NI];
   if (h->f64) {
@@ -644,6 +728,8 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
   if (!h || !in || i < 0 || i >= h->N) return fail(SOLORL_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
+  const int env_id = i;
+  { int rc_ = find_slot(h, i, &i); if (rc_) return rc_; }
   const Layout& L = h->L;
   std::vector<double> f(L.NF, 0.0);
   for (int k = 0; k < 3; k++) { f[L.pos + k] = in->pos[k]; f[L.v + k] = in->lin_vel[k]; f[L.w + k] = in->ang_vel[k]; }
@@ -656,6 +742,7 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
   for (int k = 0; k < 5; k++) f[L.dr + k] = in->dr[k];
   f[L.xyprev] = in->pos[0]; f[L.xyprev + 1] = in->pos[1];
   int iv[NI]; iv[I_TIMESTEP] = in->timestep; iv[I_MASK] = in->contact_mask; iv[I_RNG] = in->rng_counter; iv[I_NEEDRESET] = in->need_reset;
+  iv[I_ENVID] = env_id;
   if (h->f64) {
     HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(double) * (size_t)i, sizeof(double) * (size_t)h->N, f.data(), sizeof(double), sizeof(double), L.NF, hipMemcpyHostToDevice));
   } else {

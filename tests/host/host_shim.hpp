@@ -13,4 +13,5 @@ inline double2 make_double2(double x, double y) { return {x, y}; }
 inline int __popc(int x) { return __builtin_popcount((unsigned)x); }
 inline bool __any(bool x) { return x; }
 inline int __shfl_xor(int v, int) { return v; }
+inline int __mul24(int a, int b) { return a * b; }
 using std::sqrt; using std::floor; using std::fabs; using std::atan2; using std::asin;
