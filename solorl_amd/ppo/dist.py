@@ -1,0 +1,77 @@
+"""Data-parallel plumbing: one process per GPU, envs sharded across ranks (no data-path
+collective), policy gradients all-reduced over RCCL/xGMI.
+
+SURVEY.md 8(e): the gradient is ONE flat fp32 bucket -- 20 057 parameters = 80 KB for Solo12
+pointGoal / hidden 64 -- so the all-reduce is latency-bound, not link-bandwidth-bound: a single
+`all_reduce(sum)` per optimizer step on a persistent flat buffer (no per-parameter calls, no
+bucketing logic), then a scale by 1/world.  A second 3-float all-reduce reproduces the reference's
+whole-batch advantage normalisation (agents/ppo/ppo.py:35-37)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(device_type="cuda"):
+    """torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; backend nccl (= RCCL) on
+    GPUs, gloo on CPU (tests)."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if device_type == "cuda":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        else:
+            dist.init_process_group("gloo")
+    return rank(), world()
+
+
+class FlatGradBucket:
+    """All parameters' gradients viewed into one contiguous buffer (set once; autograd then
+    accumulates straight into it), all-reduced with a single collective."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        w = world()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / w)
+
+
+def global_mean_std(x, unbiased=True, eps=0.0):
+    """mean/std of a tensor sharded over ranks == torch.mean/std of the concatenation."""
+    s = torch.stack([x.sum(), (x * x).sum(), torch.tensor(float(x.numel()), device=x.device, dtype=x.dtype)])
+    if world() > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    n = s[2]
+    mean = s[0] / n
+    var = (s[1] - n * mean * mean) / (n - 1 if unbiased else n)
+    return mean, torch.sqrt(torch.clamp(var, min=0.0)) + eps
+
+
+def broadcast_parameters(module, src=0):
+    if world() > 1:
+        for p in module.parameters():
+            dist.broadcast(p.data, src)
+        for b in module.buffers():
+            dist.broadcast(b.data, src)

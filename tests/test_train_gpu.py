@@ -1,0 +1,27 @@
+"""Short end-to-end PPO run on the HIP engine (BASELINE config 3 shape at reduced length)."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ppo_train_loop_runs_and_learns_something(gpu_device, tmp_path):
+    from solorl_amd.config import load_yaml
+    from solorl_amd.ppo.train import train
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = load_yaml(os.path.join(root, "configs", "basic12.yaml"))
+    config["task"] = "walk"
+    args = types.SimpleNamespace(
+        num_agents=1024, hidden_size=64, cuda=True, gamma=0.99, tau=0.95, clip_param=0.1, ppo_epoch=2, mini_batch_size=4096,
+        lr=2.5e-4, l2_coef=0.0, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5, use_linear_lr_decay=True,
+        use_gae=True, num_env_steps=1024 * 32 * 3, seed=1, curriculum_schedule=0, log_interval=1, logdir=str(tmp_path),
+        base_checkpoint=None, save_interval=1, num_steps=32)
+    pol, hist = train(args, config)
+    assert len(hist) == 3 and all(h["fps"] > 0 for h in hist)
+    assert all(torch.isfinite(p).all() for p in pol.parameters())
+    ck = torch.load(os.path.join(str(tmp_path), "solo.pt"), weights_only=False)
+    assert set(ck.keys()) == {"update", "state_dict", "ob_rms"} and ck["ob_rms"] is None     # train.py:121-131
+    assert "pi_dist.logstd" in ck["state_dict"] and "base.critic.4.weight" in ck["state_dict"]
