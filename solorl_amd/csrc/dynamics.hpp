@@ -71,48 +71,60 @@ template <typename T> struct JointF { SV<T> S, U, c; T Dinv, u; };
 #ifndef SOLO_HOST_SHIM
 extern __shared__ __attribute__((aligned(16))) unsigned char solo_smem[];
 #endif
-template <typename T> struct RowLds {
+#ifdef SOLO_HOST_SHIM
+template <typename T> constexpr int default_lanes() { return 1; }
+#else
+template <typename T> constexpr int default_lanes() { return sizeof(T) == 4 ? 64 : 32; }
+#endif
+// LN = env columns per workgroup (compile-time, so every LDS offset below is an instruction
+// immediate): 64 (fp32) / 32 (fp64) in lane mode, 4 in team mode (16 lanes per env).
+template <typename T, int LN = default_lanes<T>()> struct RowLds {
   static constexpr int PER = 16 / sizeof(T);            // values per 16-byte chunk (4 float / 2 double)
   static constexpr int NCH = ROW_CORE / PER;            // 5 / 10
-  static constexpr int YSTRIDE = 13;                    // per-lane y record: 12 values + 1 pad (odd stride: conflict-free)
+  static constexpr int LANES = LN;
   using Chunk = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
-  struct Aux { T mu, lam, yoff, meta; };                // per row and lane: friction coefficient, impulse,
-                                                        // 3*leg (as T), meta bits (as T)
+  // Layouts (all lane-minor => conflict-free for every access width the compiler may choose;
+  // the first [row][lane][20] record layout measured 60 % bank-conflict cycles, profiles/r01_pmc_v2.txt):
+  //   core [MAX_ROWS][NCH][LANES] chunks     row record, 16-byte chunks
+  //   aux  [MAX_ROWS][4][LANES]              mu, lam, 3*leg (as T), meta bits (as T)
+  //   y    [12][LANES]                       leg delta-rates with the base held fixed
   // meta bits: 0-4 parent row, 5-6 leg, 7 is_friction, 8-9 direction (0 z, 1 x, 2 y, 3 joint)
-  int lanes, lane;
+  enum { A_MU = 0, A_LAM = 1, A_YOFF = 2, A_META = 3 };
+  int lanes, lane;   // lanes kept for the launch-side size computation; device code uses LANES
 #ifdef SOLO_HOST_SHIM
   unsigned char* base;
   SD unsigned char* smem() const { return base; }
 #else
   SD unsigned char* smem() const { return solo_smem; }
 #endif
-  SD Chunk* core() const { return reinterpret_cast<Chunk*>(smem()); }   // [MAX_ROWS][lanes][NCH]
-  SD Aux* aux() const { return reinterpret_cast<Aux*>(smem() + (size_t)MAX_ROWS * lanes * ROW_CORE * sizeof(T)); }  // [MAX_ROWS][lanes]
-  SD T* y() const { return reinterpret_cast<T*>(aux() + MAX_ROWS * lanes); }   // [lanes][YSTRIDE] leg delta-rates, base fixed
-  SD Aux& A(int r) const { return aux()[r * lanes + lane]; }
-  SD T* ylane() const { return y() + lane * YSTRIDE; }
+  SD Chunk* core() const { return reinterpret_cast<Chunk*>(smem()) + lane; }                 // + (r*NCH + c)*LANES
+  SD T* aux() const { return reinterpret_cast<T*>(smem() + (size_t)MAX_ROWS * LANES * ROW_CORE * sizeof(T)) + lane; }  // + (r*4 + f)*LANES
+  SD T* y() const { return reinterpret_cast<T*>(smem() + (size_t)MAX_ROWS * LANES * (ROW_CORE + 4) * sizeof(T)) + lane; }  // + k*LANES
+  SD T* hdr() const { return y() + 12 * LANES; }   // [8][LANES]: team-mode hand-off (nlim, nc, w[6])
+  SD T& A(int r, int f) const { return aux()[(r * 4 + f) * LANES]; }
 
   SD void store_core(int r, const T (&v)[ROW_CORE]) const {
-    Chunk* p = core() + (r * lanes + lane) * NCH;
+    Chunk* p = core() + r * (NCH * LANES);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       Chunk ch;
       if constexpr (sizeof(T) == 4) ch = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
       else ch = make_double2(v[2 * c], v[2 * c + 1]);
-      p[c] = ch;
+      p[c * LANES] = ch;
     }
   }
   SD void load_core(int r, T (&v)[ROW_CORE]) const {
-    const Chunk* p = core() + (r * lanes + lane) * NCH;
+    const Chunk* p = core() + r * (NCH * LANES);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      Chunk ch = p[c];
+      Chunk ch = p[c * LANES];
       if constexpr (sizeof(T) == 4) { v[4 * c] = ch.x; v[4 * c + 1] = ch.y; v[4 * c + 2] = ch.z; v[4 * c + 3] = ch.w; }
       else { v[2 * c] = ch.x; v[2 * c + 1] = ch.y; }
     }
   }
-  static constexpr size_t bytes(int lanes_) {
-    return (size_t)MAX_ROWS * lanes_ * (ROW_CORE + 4) * sizeof(T) + (size_t)lanes_ * YSTRIDE * sizeof(T);
+  static constexpr size_t bytes(int) {
+    // (the 8-value team header only exists in team mode: lane mode is within 1 KB of the 160 KB LDS)
+    return (size_t)MAX_ROWS * LANES * (ROW_CORE + 4) * sizeof(T) + (size_t)(LANES == 4 ? 20 : 12) * LANES * sizeof(T);
   }
 };
 
@@ -159,8 +171,27 @@ template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius) {
   return C + R.c0 * (dx * s) + R.c2 * (dz * s);
 }
 
+// sin/cos of a bounded angle (|x| < ~1e3: joint angles are limited to +-10 rad).  fp32: 3-constant
+// Cody-Waite reduction by pi/2 + minimax polynomials on [-pi/4, pi/4] (~30 VALU, <= 1 ulp), instead
+// of libm's sincosf whose large-argument path costs ~200 instructions and a dozen branches per call
+// (12 calls per sub-step were a third of phase_detect).  fp64 (validation build): libm.
 template <typename T> SD void sincos_t(T x, T& s, T& c) {
-  if constexpr (sizeof(T) == 4) sincosf(x, &s, &c); else sincos(x, &s, &c);
+  if constexpr (sizeof(T) == 4) {
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                          fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+  } else {
+    sincos(x, &s, &c);
+  }
 }
 
 // ---------------------------------------------------------------- leg kinematics (shared)
@@ -234,8 +265,8 @@ template <typename T, int ROBOT> struct SubCtx {
 
 // park one half-built row in LDS: f0 (force transmitted to the base), JL (raw joint torques),
 // Y (leg response, base fixed), the contact point P and penetration for the finishing loop.
-template <typename T>
-SD void park_row(const RowLds<T>& lds, int slot, SV<T> f0, const T (&JL)[3], const T (&Y)[3], V3<T> P, T pen, T lam0, T mu,
+template <typename T, typename LDS>
+SD void park_row(const LDS& lds, int slot, SV<T> f0, const T (&JL)[3], const T (&Y)[3], V3<T> P, T pen, T lam0, T mu,
                  int meta) {
   T core[ROW_CORE];
   core[0] = f0.a.x; core[1] = f0.a.y; core[2] = f0.a.z; core[3] = f0.l.x; core[4] = f0.l.y; core[5] = f0.l.z;
@@ -243,9 +274,9 @@ SD void park_row(const RowLds<T>& lds, int slot, SV<T> f0, const T (&JL)[3], con
   core[9] = P.x; core[10] = P.y; core[11] = P.z; core[12] = pen; core[13] = lam0; core[14] = T(0);
   core[15] = Y[0]; core[16] = Y[1]; core[17] = Y[2]; core[18] = T(0); core[19] = T(0);
   lds.store_core(slot, core);
-  typename RowLds<T>::Aux a;
-  a.mu = mu; a.lam = T(0); a.yoff = T(3 * ((meta >> 5) & 3)); a.meta = T(meta);
-  lds.A(slot) = a;
+  using R = LDS;
+  lds.A(slot, R::A_MU) = mu; lds.A(slot, R::A_LAM) = T(0);
+  lds.A(slot, R::A_YOFF) = T(3 * ((meta >> 5) & 3)); lds.A(slot, R::A_META) = T(meta);
 }
 
 // ---------------------------------------------------------------- phase 1: collision detection
@@ -311,8 +342,8 @@ SNI void phase_detect(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp) {
 
 // ---------------------------------------------------------------- phase 2 (x4): one leg
 // FK + ABA passes 1-2, leg response (G, qdd0), parked limit and contact rows of this leg
-template <typename T, int ROBOT, int L>
-SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const RowLds<T> lds) {
+template <typename T, int ROBOT, int L, typename LDS>
+SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   constexpr int L0 = 1 + L * (NJ + 1);
@@ -461,8 +492,8 @@ SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
 }
 
 // ---------------------------------------------------------------- phase 3: base solve + finish rows
-template <typename T, int ROBOT>
-SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const RowLds<T> lds) {
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ, NQ = RB::NQ;
   const T dt = pp.dt;
@@ -509,9 +540,10 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
   for (int L = 0; L < 4; L++)
 #pragma unroll
     for (int k = 0; k < 3; k++) qsl[L][k] = k < NJ ? C.qds[L * NJ + k] : T(0);
-  T* const yl = lds.ylane();
+  constexpr int LN = LDS::LANES;
+  T* const yl = lds.y();
 #pragma unroll
-  for (int k = 0; k < 12; k++) yl[k] = T(0);
+  for (int k = 0; k < 12; k++) yl[k * LN] = T(0);
   const V3<T> bw = C.ps.w, bv = C.ps.v;
   V3<T> vdot = a0.l + cross(bw, bv); vdot.z -= pp.gravity;
   SV<T> ub;
@@ -524,12 +556,12 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
     if (r < nrows) {
       T c[ROW_CORE];
       lds.load_core(r, c);
-      const int meta = (int)lds.A(r).meta;
+      const int meta = (int)lds.A(r, LDS::A_META);
       const int leg = (meta >> 5) & 3, dir = (meta >> 8) & 3;
       const SV<T> f0{{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
       const V3<T> P = mk(c[9], c[10], c[11]);
       const V3<T> u = mk(dir == 1 ? T(1) : T(0), dir == 2 ? T(1) : T(0), dir == 0 ? T(1) : T(0));
-      T* yp = yl + leg * 3;
+      T* yp = yl + leg * 3 * LN;
       const T q0 = leg == 0 ? qsl[0][0] : leg == 1 ? qsl[1][0] : leg == 2 ? qsl[2][0] : qsl[3][0];
       const T q1 = leg == 0 ? qsl[0][1] : leg == 1 ? qsl[1][1] : leg == 2 ? qsl[2][1] : qsl[3][1];
       const T q2 = leg == 0 ? qsl[0][2] : leg == 1 ? qsl[1][2] : leg == 2 ? qsl[2][2] : qsl[3][2];
@@ -548,9 +580,9 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
       const T lam0 = c[13];
       c[9] = W.a.x; c[10] = W.a.y; c[11] = W.a.z; c[12] = W.l.x; c[13] = W.l.y; c[14] = W.l.z; c[18] = rhs; c[19] = dinv;
       lds.store_core(r, c);
-      lds.A(r).lam = lam0;
+      lds.A(r, LDS::A_LAM) = lam0;
       w = fma6(W, lam0, w);   // warm start: dV += M^-1 J^T lam0
-      yp[0] += c[15] * lam0; yp[1] += c[16] * lam0; yp[2] += c[17] * lam0;
+      yp[0] += c[15] * lam0; yp[LN] += c[16] * lam0; yp[2 * LN] += c[17] * lam0;
     }
   }
   C.w = w;
@@ -563,18 +595,17 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
 // impulse, friction coefficient and leg id are fetched while row r is computed; a friction row's
 // parent is found arithmetically (parent = nlim + (r - nlim - nc)/2), so there is no dependent
 // LDS chain.  Accumulators: base delta-velocity w in registers, leg delta-rates y in LDS.
-template <typename T, int ROBOT>
-SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
-  using Chunk = typename RowLds<T>::Chunk;
-  using Aux = typename RowLds<T>::Aux;
-  constexpr int NCH = RowLds<T>::NCH;
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const LDS lds) {
+  using R_ = LDS;
+  using Chunk = typename R_::Chunk;
+  constexpr int NCH = R_::NCH, LN = R_::LANES;
   const int nlt = C.nlim_total, nc = C.nc;
   const int nrows = nlt + 3 * nc, rfric = nlt + nc;
   SV<T> w = C.w;
-  const int L = lds.lanes;
-  const Chunk* const corev = lds.core() + lds.lane * NCH;   // row r at corev + r*L*NCH
-  Aux* const auxv = lds.aux() + lds.lane;                    // row r at auxv + r*L
-  T* const yl = lds.ylane();
+  const Chunk* const corev = lds.core();   // row r, chunk c at corev[(r*NCH + c)*LN]
+  T* const auxv = lds.aux();               // row r, field f at auxv[(r*4 + f)*LN]
+  T* const yl = lds.y();                   // accumulator k at yl[k*LN]
   int wmax = nrows;   // wave-uniform maximum row count
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { int t = __shfl_xor(wmax, o); wmax = t > wmax ? t : wmax; }
@@ -586,19 +617,19 @@ SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
   // computed register values are forwarded instead of waiting for an LDS store->load round trip.
   struct Row { T c[ROW_CORE]; T mu, lam, lamp, y0, y1, y2; int yoff, par; };
   auto fetch = [&](int rr, Row& R) {
-    const Chunk* p = corev + __mul24(rr, L * NCH);
+    const Chunk* p = corev + __mul24(rr, NCH * LN);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      Chunk ch = p[c];
+      Chunk ch = p[c * LN];
       if constexpr (sizeof(T) == 4) { R.c[4 * c] = ch.x; R.c[4 * c + 1] = ch.y; R.c[4 * c + 2] = ch.z; R.c[4 * c + 3] = ch.w; }
       else { R.c[2 * c] = ch.x; R.c[2 * c + 1] = ch.y; }
     }
-    const Aux a = auxv[__mul24(rr, L)];
-    R.mu = a.mu; R.lam = a.lam; R.yoff = (int)a.yoff;
+    const T* a = auxv + __mul24(rr, 4 * LN);
+    R.mu = a[R_::A_MU * LN]; R.lam = a[R_::A_LAM * LN]; R.yoff = (int)a[R_::A_YOFF * LN] * LN;
     int pi = nlt + ((rr - rfric) >> 1);                  // friction parent (clamped: harmless for other rows)
     R.par = pi < 0 ? 0 : pi;
-    R.lamp = auxv[__mul24(R.par, L)].lam;
-    R.y0 = yl[R.yoff]; R.y1 = yl[R.yoff + 1]; R.y2 = yl[R.yoff + 2];
+    R.lamp = auxv[__mul24(R.par, 4 * LN) + R_::A_LAM * LN];
+    R.y0 = yl[R.yoff]; R.y1 = yl[R.yoff + LN]; R.y2 = yl[R.yoff + 2 * LN];
   };
   // update row r (in R); N receives row r+1, fetched before the arithmetic, patched after it
   auto step = [&](int r, Row& R, Row& N) {
@@ -617,8 +648,8 @@ SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
     w.l.x += R.c[12] * delta; w.l.y += R.c[13] * delta; w.l.z += R.c[14] * delta;
     const T y0 = R.y0 + R.c[15] * delta, y1 = R.y1 + R.c[16] * delta, y2 = R.y2 + R.c[17] * delta;
     const int rw = live ? r : last;
-    auxv[__mul24(rw, L)].lam = sum;                      // (dead lanes rewrite their last row's own value)
-    yl[R.yoff] = y0; yl[R.yoff + 1] = y1; yl[R.yoff + 2] = y2;
+    auxv[__mul24(rw, 4 * LN) + R_::A_LAM * LN] = sum;    // (dead lanes rewrite their last row's own value)
+    yl[R.yoff] = y0; yl[R.yoff + LN] = y1; yl[R.yoff + 2 * LN] = y2;
     // forward what the prefetch could not have seen yet
     const bool samey = N.yoff == R.yoff;
     N.y0 = samey ? y0 : N.y0; N.y1 = samey ? y1 : N.y1; N.y2 = samey ? y2 : N.y2;
@@ -639,18 +670,18 @@ SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const RowLds<T> lds) {
 #pragma unroll
   for (int l = 0; l < 4; l++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) C.y[l][k] = yl[l * 3 + k];
+    for (int k = 0; k < 3; k++) C.y[l][k] = yl[(l * 3 + k) * LN];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int p = 12 + i;
-    C.lam_n[i] = ((C.mask >> p) & 1) ? auxv[(nlt + __popc(C.mask & ((1 << p) - 1))) * L].lam : T(0);
+    C.lam_n[i] = ((C.mask >> p) & 1) ? lds.A(nlt + __popc(C.mask & ((1 << p) - 1)), R_::A_LAM) : T(0);
   }
 }
 
 // ---------------------------------------------------------------- phase 5: apply + integrate
 // delta-velocities (clamp K5), impulse cache, semi-implicit Euler (K1)
-template <typename T, int ROBOT>
-SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const RowLds<T> lds) {
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS lds) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   const T dt = pp.dt;
@@ -659,7 +690,7 @@ SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_pr
     constexpr int p = decltype(pc)::value;
     T l = T(0);
     if constexpr (p < 12) {
-      if ((mask >> p) & 1) l = lds.A(nlt + __popc(mask & ((1 << p) - 1))).lam;
+      if ((mask >> p) & 1) l = lds.A(nlt + __popc(mask & ((1 << p) - 1)), LDS::A_LAM);
     } else l = C.lam_n[p - 12];
     lam_prev[(size_t)p * nstride] = l;
   });
@@ -693,19 +724,191 @@ SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_pr
   C.ps = st;
 }
 
+#ifndef SOLO_HOST_SHIM
+// ---------------------------------------------------------------- team mode (small batches)
+// 16 lanes (one DPP row) per env, 4 envs per wavefront.  The team leader (lane 0 of the row) runs the
+// phases above; the PGS sweep -- the critical path -- is shared by the whole row: the 18 accumulator
+// components [w(6), y_leg0..3 (12)] live one (two for lanes 0,1) per lane, a row update is
+//   partial = J[c]*acc[c]  ->  4-step DPP butterfly sum  ->  replicated clamp  ->  acc[c] += B[c]*delta
+// i.e. ~30 instructions per row instead of ~85 for a lone lane doing all 18 multiply-adds.
+template <typename T> SD T team_sum16(T x) {
+  if constexpr (sizeof(T) == 4) {
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+  } else {
+    x += __shfl_xor(x, 1, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 8, 16);
+  }
+  return x;
+}
+
+// Team-sweep row storage (after the RowLds<T,4> region): per env column
+//   rec  [TR][4][40]   18 (J_c, B_c) pairs, one per accumulator component c (zero for the components of
+//                      other legs, so no masks in the loop) + 2 zero pairs
+//   sca  [TR][4][8]    rhs, 1/diag, mu, lo-multiplier (-1 friction / 0 otherwise), byte offset of the
+//                      parent impulse in `lam` (friction) or of the +inf slot (otherwise), 3 pad
+//   lam  [TR+1][4]     impulses; slot TR holds +1e30 (the "parent" of unilateral rows: hi = mu*1e30)
+// TR = MAX_ROWS + 1: row `nrows` of every env is a null row, so teams with fewer rows than the wave
+// maximum spin on it instead of needing liveness selects.
+template <typename T, typename LDS> struct TeamRows {
+  static constexpr int TR = MAX_ROWS + 1, REC = 40, SCA = 8;
+  static constexpr size_t off_rec = LDS::bytes(4);
+  static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
+  static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
+  static constexpr size_t bytes = off_lam + (size_t)(TR + 1) * 4 * sizeof(T);
+  SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + r*4*REC
+  SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + r*4*SCA
+  SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + r*4
+};
+
+// leader: expand the finished lane-layout rows into team records
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_team_expand(const SubCtx<T, ROBOT>& C, const LDS lds) {
+  using TRW = TeamRows<T, LDS>;
+  const int col = lds.lane;
+  const int nlt = C.nlim_total, nc = C.nc, nrows = nlt + 3 * nc, rfric = nlt + nc;
+  T* const rec = TRW::rec(col); T* const sca = TRW::sca(col); T* const lam = TRW::lam(col);
+  lam[TRW::TR * 4] = T(1e30);
+  for (int r = 0; r <= nrows; r++) {
+    T* q = rec + r * (4 * TRW::REC);
+    T* sc = sca + r * (4 * TRW::SCA);
+#pragma unroll
+    for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
+    if (r == nrows) {   // null row
+      sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0);
+      reinterpret_cast<int*>(sc)[4] = (TRW::TR * 4) * (int)sizeof(T);
+      lam[r * 4] = T(0);
+      break;
+    }
+    T c[ROW_CORE];
+    lds.load_core(r, c);
+    const int leg = (int)lds.A(r, LDS::A_YOFF) / 3;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { q[2 * k] = c[k]; q[2 * k + 1] = c[9 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { q[2 * (6 + 3 * leg + k)] = c[6 + k]; q[2 * (6 + 3 * leg + k) + 1] = c[15 + k]; }
+    const bool fr = r >= rfric;
+    sc[0] = c[18]; sc[1] = c[19];
+    sc[2] = fr ? lds.A(r, LDS::A_MU) : T(1); sc[3] = fr ? T(-1) : T(0);
+    const int par = fr ? nlt + ((r - rfric) >> 1) : TRW::TR;
+    reinterpret_cast<int*>(sc)[4] = (par * 4) * (int)sizeof(T);
+    lam[r * 4] = lds.A(r, LDS::A_LAM);
+  }
+}
+
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
+  using TRW = TeamRows<T, LDS>;
+  constexpr int LN = LDS::LANES;
+  const int col = lds.lane;
+  T* const hdr = lds.hdr();
+  const int nrows = (int)hdr[0] + 3 * (int)hdr[LN];
+  int wmax = nrows;
+#pragma unroll
+  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
+  // this lane's accumulator components: c0 = t, c1 = 16 + t (lanes 0,1) or the zero pair 18
+  const bool two = t < 2;
+  const int c1 = two ? 16 + t : 18;
+  T acc0 = t < 6 ? hdr[(2 + t) * LN] : lds.y()[(t - 6) * LN];
+  T acc1 = two ? lds.y()[(10 + t) * LN] : T(0);
+  const char* const rec0 = reinterpret_cast<const char*>(TRW::rec(col)) + 2 * t * sizeof(T);
+  const int d1 = 2 * (c1 - t) * (int)sizeof(T);
+  const char* const sca0 = reinterpret_cast<const char*>(TRW::sca(col));
+  char* const lam0 = reinterpret_cast<char*>(TRW::lam(col));
+  constexpr int S_REC = 4 * TRW::REC * (int)sizeof(T), S_SCA = 4 * TRW::SCA * (int)sizeof(T), S_LAM = 4 * (int)sizeof(T);
+  using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+  struct Row { P2 jb0, jb1; T rhs, dinv, mu, lom, lam; int poff; };
+  auto fetch = [&](int rr, Row& R) {
+    R.jb0 = *reinterpret_cast<const P2*>(rec0 + rr * S_REC);
+    R.jb1 = *reinterpret_cast<const P2*>(rec0 + rr * S_REC + d1);
+    const T* sc = reinterpret_cast<const T*>(sca0 + rr * S_SCA);
+    R.rhs = sc[0]; R.dinv = sc[1]; R.mu = sc[2]; R.lom = sc[3];
+    R.poff = reinterpret_cast<const int*>(sc)[4];
+    R.lam = *reinterpret_cast<const T*>(lam0 + rr * S_LAM);
+  };
+  auto step = [&](int r, Row& R, Row& N) {
+    const int rc = r < nrows ? r : nrows;                 // past the end: this env's null row
+    const int rn = r + 1 < nrows ? r + 1 : nrows;
+    fetch(rn, N);
+    const T lamp = *reinterpret_cast<const T*>(lam0 + R.poff);   // issued after the previous row's store: always fresh
+    const T jdv = team_sum16(R.jb0.x * acc0 + R.jb1.x * acc1);
+    const T hi = R.mu * lamp, lo = R.lom * hi;
+    T sum = R.lam + (R.rhs - jdv * R.dinv);
+    if constexpr (sizeof(T) == 4) sum = __builtin_amdgcn_fmed3f(sum, lo, hi);
+    else sum = sum < lo ? lo : (sum > hi ? hi : sum);
+    const T delta = sum - R.lam;
+    acc0 += R.jb0.y * delta; acc1 += R.jb1.y * delta;
+    if (t == 0) *reinterpret_cast<T*>(lam0 + rc * S_LAM) = sum;
+    N.lam = rn == rc ? sum : N.lam;                       // (only the null row can repeat; its sum is 0 anyway)
+  };
+#pragma unroll 1
+  for (int it = 0; it < iterations; it++) {
+    Row A, B;
+    fetch(0, A);
+#pragma unroll 1
+    for (int r = 0; r < wmax; r += 2) {
+      step(r, A, B);
+      step(r + 1, B, A);
+    }
+  }
+  // accumulators back to LDS for the leader
+  if (t < 6) hdr[(2 + t) * LN] = acc0; else lds.y()[(t - 6) * LN] = acc0;
+  if (two) lds.y()[(10 + t) * LN] = acc1;
+}
+
+template <typename T, int ROBOT, typename LDS>
+SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds, int t, bool lead) {
+  constexpr int LN = LDS::LANES;
+  using TRW = TeamRows<T, LDS>;
+  if (lead) {
+    phase_detect<T, ROBOT>(C, pp);
+    phase_leg<T, ROBOT, 0, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 1, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 2, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 3, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_base<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_team_expand<T, ROBOT, LDS>(C, lds);
+    T* hdr = lds.hdr();
+    hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
+    hdr[2 * LN] = C.w.a.x; hdr[3 * LN] = C.w.a.y; hdr[4 * LN] = C.w.a.z;
+    hdr[5 * LN] = C.w.l.x; hdr[6 * LN] = C.w.l.y; hdr[7 * LN] = C.w.l.z;
+  }
+  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
+  if (lead) {
+    const T* hdr = lds.hdr();
+    C.w.a = mk(hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]); C.w.l = mk(hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]);
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) C.y[l][k] = lds.y()[(l * 3 + k) * LN];
+    const T* lam = TRW::lam(lds.lane);
+    // impulses back into the lane-layout aux (phase_integrate reads the base primitives' there)
+    for (int r = C.nlim_total; r < C.nlim_total + C.nc; r++) lds.A(r, LDS::A_LAM) = lam[r * 4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int p = 12 + i;
+      C.lam_n[i] = ((C.mask >> p) & 1) ? lam[(C.nlim_total + __popc(C.mask & ((1 << p) - 1))) * 4] : T(0);
+    }
+    phase_integrate<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+  }
+  return C.mask;
+}
+#endif  // !SOLO_HOST_SHIM
+
 // ---------------------------------------------------------------- one physics sub-step
 // C.ps / C.tau: state and the joint torques applied during this sub-step.  lam_prev: per-primitive
 // warm-start impulses (global memory, stride = nstride).  Returns the contact bit mask.
-template <typename T, int ROBOT>
-SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const RowLds<T>& lds) {
+template <typename T, int ROBOT, typename LDS>
+SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds) {
   phase_detect<T, ROBOT>(C, pp);
-  phase_leg<T, ROBOT, 0>(C, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 1>(C, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 2>(C, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 3>(C, pp, lam_prev, nstride, lds);
-  phase_base<T, ROBOT>(C, pp, lam_prev, nstride, lds);
-  phase_pgs<T, ROBOT>(C, pp.iterations, lds);
-  phase_integrate<T, ROBOT>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 0, LDS>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 1, LDS>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 2, LDS>(C, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 3, LDS>(C, pp, lam_prev, nstride, lds);
+  phase_base<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+  phase_pgs<T, ROBOT, LDS>(C, pp.iterations, lds);
+  phase_integrate<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
   return C.mask;
 }
 

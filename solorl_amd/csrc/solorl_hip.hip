@@ -220,23 +220,36 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
 // latency/issue bound and independent per env, so for small batches the host launches MORE waves
 // with FEWER active lanes each (one wave per SIMD: 4096 envs -> 1024 waves of 4 lanes) instead of
 // 64 full waves on a 1024-SIMD chip.
-template <typename T, int ROBOT>
-__global__ void __launch_bounds__(64)
-step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
-            Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
+// TEAM = false (lane mode): one env per lane, 64 envs per wavefront -- best throughput for large batches.
+// TEAM = true  (team mode): 16 lanes per env, 4 envs per wavefront; the row leader (t == 0) runs the
+// env logic and the dynamics phases, the whole row shares the PGS sweep (dynamics.hpp) -- shortest
+// latency for small batches, where the launch lasts as long as the heaviest env's sequential sweep.
+template <typename T, int ROBOT, bool TEAM>
+SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
+                  const Layout& L, int N, const EnvParams& P, const PhysParams<T>& pp, const float* __restrict__ actions,
+                  const Outputs& out, int mode) {
   using RB = Robot<ROBOT>;
   constexpr int NQ = RB::NQ;
-  const int lane = threadIdx.x;
-  const int EPB = blockDim.x;
-  const size_t e = (size_t)blockIdx.x * EPB + lane;
-  if (e >= (size_t)N) return;
-  RowLds<T> lds; lds.lanes = EPB; lds.lane = lane;
-  const size_t env = (size_t)si[(size_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
+  using LDS = typename std::conditional<TEAM, RowLds<T, 4>, RowLds<T>>::type;
+  constexpr int EPB = LDS::LANES;          // envs per workgroup: compile-time (LDS immediates)
+  const int t = TEAM ? (threadIdx.x & 15) : 0;
+  const int col = TEAM ? (threadIdx.x >> 4) : threadIdx.x;
+  size_t e = (size_t)blockIdx.x * EPB + col;
+  const bool valid = e < (size_t)N;
+  if (!TEAM && !valid) return;
+  if (!valid) e = (size_t)N - 1;           // team mode keeps every lane alive for the wave-level exchanges
+  const bool lead = valid && t == 0;
+  LDS lds; lds.lanes = EPB; lds.lane = col;
+  size_t env = 0;
   Env<T, NQ> E;
-  load_env(E, sf, si, L, (size_t)N, e);
+  if (lead) {
+    env = (size_t)si[(size_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
+    load_env(E, sf, si, L, (size_t)N, e);
+  }
 
   // ---- A3 apply_action
   T tau[NQ], asq = T(0);
+  if (lead) {
 #pragma unroll
   for (int j = 0; j < NQ; j++) {
     T a = mode == MODE_STEP ? (T)actions[env * NQ + j] : T(0);
@@ -249,9 +262,10 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
     }
     if (mode != MODE_STEP) tau[j] = T(0);
   }
+  }
 
   // ---- A4 simulator_step: history push (pre-step state), frame_skip sub-steps
-  if (L.H > 0) {
+  if (lead && L.H > 0) {
     T cs[DMAX];
     current_state<T, ROBOT>(E, P.task, cs);
 #pragma unroll
@@ -270,10 +284,21 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
       const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
 #pragma unroll
       for (int j = 0; j < NQ; j++) C.tau[j] = tau[j] * sc;
-      E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
+      if constexpr (TEAM) {
+        if (!valid && t == 0) {   // idle team: zero rows, a null row to spin on
+          lds.hdr()[0] = T(0); lds.hdr()[EPB] = T(0);
+          SubCtx<T, ROBOT> Z; Z.nlim_total = 0; Z.nc = 0;
+          phase_team_expand<T, ROBOT, LDS>(Z, lds);
+        }
+        const int m = substep_team<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds, t, lead);
+        if (lead) E.mask = m;
+      } else {
+        E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
+      }
     }
     E.ps = C.ps;
   }
+  if (!lead) return;
   if (P.task == SOLORL_TASK_POINTGOAL && mode == MODE_STEP) {
     T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
     T np = sqrt(dx * dx + dy * dy);
@@ -335,6 +360,20 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
   if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, env, snf, sni, M, P);
   write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, env, P.task, out.obs);
   store_env(E, sf, si, L, (size_t)N, e);
+}
+
+template <typename T, int ROBOT>
+__global__ void __launch_bounds__(64)
+step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
+            Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
+  step_body<T, ROBOT, false>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
+}
+
+template <typename T, int ROBOT>
+__global__ void __launch_bounds__(64)
+step_kernel_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
+                 Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
+  step_body<T, ROBOT, true>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
 }
 
 template <typename T, int ROBOT>
@@ -442,6 +481,7 @@ struct solorl_env {
   double goal_radius = 2.0;
   int epw = 64;   // envs per wavefront (lanes per workgroup)
   bool spread = true;
+  bool team = false;   // 16 lanes per env (small batches)
 };
 
 namespace {
@@ -466,8 +506,18 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
 
 template <typename T, int ROBOT>
 int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
+  if (h->team) {
+    auto kt = step_kernel_team<T, ROBOT>;
+    dim3 grid((N + 3) / 4), block(64);
+    using TeamLds = RowLds<T, 4>;
+    const size_t team_smem = TeamRows<T, TeamLds>::bytes;
+    hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
+                       make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   auto kern = step_kernel<T, ROBOT>;
-  const int EPB = N < h->epw ? N : h->epw;
+  const int EPB = RowLds<T>::LANES;
   // small workgroups would be packed several to a CU (sharing its LDS pipe and issue slots) while other
   // CUs idle; asking for (almost) the whole LDS forces one workgroup per CU.
   size_t smem = RowLds<T>::bytes(EPB);
@@ -576,6 +626,8 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     if (const char* ev = getenv("SOLORL_ENVS_PER_WAVE")) { int v = atoi(ev); if (v >= 1 && v <= 64) epw = v; }
     if (h->f64 && epw > 32) epw = 32;
     if (const char* ev = getenv("SOLORL_SPREAD")) h->spread = atoi(ev) != 0;
+    h->team = num_envs <= 8192;
+    if (const char* ev = getenv("SOLORL_TEAM")) h->team = atoi(ev) != 0;
     h->epw = epw;
   }
   auto cleanup = [&](int code) { solorl_destroy(h); return code; };

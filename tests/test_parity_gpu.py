@@ -222,3 +222,45 @@ def test_pointgoal_bookkeeping_full_size(gpu_device):
         o, r, d, info = env.step_inplace(a)
     goal = o[:, 40:42] * 2
     assert (goal.abs() < 3.0).all() and (goal.abs() >= 2.0).any()             # goal_radius 2 -> 3 after curriculum
+
+
+def test_fp64_engine_matches_oracle_tightly(gpu_device):
+    """precision = f64: the SAME kernels instantiated in double agree with the oracle to rounding,
+    i.e. the HIP code computes the oracle's algorithm; fp32 differences are then pure precision."""
+    from solorl_amd.config import PRECISION_F64
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK, precision=PRECISION_F64)
+    N = 32
+    env, orc = make(c, N, seed=4)
+    og = env.reset().cpu().numpy(); oo = orc.reset()
+    assert obs_diff(og, oo, c.state_dim).max() < 1e-5          # (obs are emitted as float32)
+    rng = np.random.default_rng(2)
+    errs = []
+    for t in range(12):
+        for i in range(N):
+            orc.set_state(i, env.get_state(i))
+        a = (0.3 * rng.uniform(-1, 1, size=(N, 12))).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda()); orc.step(a.astype(np.float64))
+        for i in range(N):
+            sg, so = env.get_state(i), orc.get_state(i)
+            assert sg.contact_mask == so.contact_mask
+            errs.append(np.abs(np.array(sg.q) - np.array(so.q)).max())
+    errs = np.array(errs)
+    assert np.median(errs) < 1e-11 and np.percentile(errs, 90) < 1e-7
+
+
+def test_fp64_standing_trajectory(gpu_device):
+    from solorl_amd.config import PRECISION_F64
+    c = stand_cfg(); c.precision = PRECISION_F64
+    env, _ = make(c, 4)
+    env.reset()
+    s = load_state("stand_pd_start.json")
+    for i in range(4):
+        env.set_state(i, s)
+    gold = np.load(os.path.join(GOLDEN, "stand_pd_traj.npz"))
+    worst = 0.0
+    for t in range(1000):
+        env.step(torch.tensor(np.tile(stand_action(t), (4, 1)), dtype=torch.float32, device="cuda:0"))
+        if (t + 1) % 50 == 0:
+            worst = max(worst, np.abs(np.array(env.get_state(0).q) - gold["q"][(t + 1) // 50 - 1]).max())
+    # actions pass through float32 at the boundary (agents/ppo/envs.py:192), the oracle fixture used float64 actions
+    assert worst < 2e-5, worst
