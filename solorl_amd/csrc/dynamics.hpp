@@ -492,10 +492,13 @@ SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
 }
 
 // ---------------------------------------------------------------- phase 3: base solve + finish rows
+// base_solve: parks the base primitives' rows, inverts the base articulated inertia, computes the
+// unconstrained velocities u* = u + dt*udot (C.ub, C.qds) and returns Lam and the padded leg rates.
 template <typename T, int ROBOT, typename LDS>
-SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS& lds,
+                   Sym6<T>& Lam, T (&qsl)[4][3]) {
   using RB = Robot<ROBOT>;
-  constexpr int NJ = RB::NJ, NQ = RB::NQ;
+  constexpr int NJ = RB::NJ;
   const T dt = pp.dt;
   const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
   const int nrows = nlt + 3 * nc;
@@ -524,32 +527,59 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
     park_row(lds, 0, zero6<T>(), Z, Z, mk(T(0), T(0), T(0)), T(0), T(0), T(0), 0);
   }
   // base acceleration (gravity via the accelerating-frame trick), u* = u + dt*udot
-  const Sym6<T> Lam = spd_inverse(C.Ibase);
+  Lam = spd_inverse(C.Ibase);
   const SV<T> a0 = mul(Lam, C.pbase) * T(-1);
   static_for<4>([&](auto lc) {
     constexpr int L = decltype(lc)::value;
 #pragma unroll
     for (int k = 0; k < NJ; k++) {
       T qdd = C.LR[L].qdd0[k] - dot(C.LR[L].G[k], a0);
-      T v = clampv(C.ps.qd[L * NJ + k] + dt * qdd, pp.vmax);
-      C.qds[L * NJ + k] = v;
+      C.qds[L * NJ + k] = clampv(C.ps.qd[L * NJ + k] + dt * qdd, pp.vmax);
     }
   });
-  T qsl[4][3];   // unconstrained joint rates per leg, padded to 3
 #pragma unroll
   for (int L = 0; L < 4; L++)
 #pragma unroll
     for (int k = 0; k < 3; k++) qsl[L][k] = k < NJ ? C.qds[L * NJ + k] : T(0);
-  constexpr int LN = LDS::LANES;
-  T* const yl = lds.y();
-#pragma unroll
-  for (int k = 0; k < 12; k++) yl[k * LN] = T(0);
   const V3<T> bw = C.ps.w, bv = C.ps.v;
   V3<T> vdot = a0.l + cross(bw, bv); vdot.z -= pp.gravity;
   SV<T> ub;
   ub.a = mk(clampv(bw.x + dt * a0.a.x, pp.vmax), clampv(bw.y + dt * a0.a.y, pp.vmax), clampv(bw.z + dt * a0.a.z, pp.vmax));
   ub.l = mk(clampv(bv.x + dt * vdot.x, pp.vmax), clampv(bv.y + dt * vdot.y, pp.vmax), clampv(bv.z + dt * vdot.z, pp.vmax));
   C.ub = ub;
+}
+
+// finish one parked row: W = Lam f0, 1/diagonal, right-hand side (speculative / ERP, or friction)
+template <typename T>
+SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const SV<T>& ub, T q0, T q1, T q2,
+                   const PhysParams<T>& pp, SV<T>& W, T& rhs, T& dinv) {
+  const int dir = (meta >> 8) & 3;
+  const SV<T> f0{{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
+  const V3<T> P = mk(c[9], c[10], c[11]);
+  const V3<T> u = mk(dir == 1 ? T(1) : T(0), dir == 2 ? T(1) : T(0), dir == 0 ? T(1) : T(0));
+  const T rel = dot(cross(P, u), ub.a) + dot(u, ub.l) + c[6] * q0 + c[7] * q1 + c[8] * q2;
+  W = mul(Lam, f0);
+  const T denom = dot(f0, W) + c[6] * c[15] + c[7] * c[16] + c[8] * c[17];
+  dinv = T(1) / denom;
+  if (meta & 128) rhs = -rel * dinv;
+  else {
+    const T pen = c[12];
+    T pos = T(0), vel = -rel;
+    if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * pp.erp * pp.inv_dt;
+    rhs = (pos + vel) * dinv;
+  }
+}
+
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+  constexpr int LN = LDS::LANES;
+  Sym6<T> Lam; T qsl[4][3];
+  base_solve<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds, Lam, qsl);
+  const SV<T> ub = C.ub;
+  const int nrows = C.nlim_total + 3 * C.nc;
+  T* const yl = lds.y();
+#pragma unroll
+  for (int k = 0; k < 12; k++) yl[k * LN] = T(0);
   // finish the parked rows (W = Lam f0, diagonal, right-hand side, warm start)
   SV<T> w = zero6<T>();
   for (int r = 0; __any(r < nrows); r++) {
@@ -557,26 +587,13 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
       T c[ROW_CORE];
       lds.load_core(r, c);
       const int meta = (int)lds.A(r, LDS::A_META);
-      const int leg = (meta >> 5) & 3, dir = (meta >> 8) & 3;
-      const SV<T> f0{{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
-      const V3<T> P = mk(c[9], c[10], c[11]);
-      const V3<T> u = mk(dir == 1 ? T(1) : T(0), dir == 2 ? T(1) : T(0), dir == 0 ? T(1) : T(0));
+      const int leg = (meta >> 5) & 3;
       T* yp = yl + leg * 3 * LN;
       const T q0 = leg == 0 ? qsl[0][0] : leg == 1 ? qsl[1][0] : leg == 2 ? qsl[2][0] : qsl[3][0];
       const T q1 = leg == 0 ? qsl[0][1] : leg == 1 ? qsl[1][1] : leg == 2 ? qsl[2][1] : qsl[3][1];
       const T q2 = leg == 0 ? qsl[0][2] : leg == 1 ? qsl[1][2] : leg == 2 ? qsl[2][2] : qsl[3][2];
-      const T rel = dot(cross(P, u), ub.a) + dot(u, ub.l) + c[6] * q0 + c[7] * q1 + c[8] * q2;
-      const SV<T> W = mul(Lam, f0);
-      const T denom = dot(f0, W) + c[6] * c[15] + c[7] * c[16] + c[8] * c[17];
-      const T dinv = T(1) / denom;
-      T rhs;
-      if (meta & 128) rhs = -rel * dinv;
-      else {
-        const T pen = c[12];
-        T pos = T(0), vel = -rel;
-        if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * pp.erp * pp.inv_dt;
-        rhs = (pos + vel) * dinv;
-      }
+      SV<T> W; T rhs, dinv;
+      finish_row(c, meta, Lam, ub, q0, q1, q2, pp, W, rhs, dinv);
       const T lam0 = c[13];
       c[9] = W.a.x; c[10] = W.a.y; c[11] = W.a.z; c[12] = W.l.x; c[13] = W.l.y; c[14] = W.l.z; c[18] = rhs; c[19] = dinv;
       lds.store_core(r, c);
@@ -752,48 +769,89 @@ template <typename T> SD T team_sum16(T x) {
 // TR = MAX_ROWS + 1: row `nrows` of every env is a null row, so teams with fewer rows than the wave
 // maximum spin on it instead of needing liveness selects.
 template <typename T, typename LDS> struct TeamRows {
-  static constexpr int TR = MAX_ROWS + 1, REC = 40, SCA = 8;
+  static constexpr int TR = MAX_ROWS + 1, REC = 40, SCA = 8, BC = 56;
   static constexpr size_t off_rec = LDS::bytes(4);
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
-  static constexpr size_t bytes = off_lam + (size_t)(TR + 1) * 4 * sizeof(T);
+  static constexpr size_t off_bc = off_lam + (size_t)(TR + 1) * 4 * sizeof(T);
+  static constexpr size_t bytes = off_bc + (size_t)4 * BC * sizeof(T);
   SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + r*4*REC
   SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + r*4*SCA
   SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + r*4
+  SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12
 };
 
-// leader: expand the finished lane-layout rows into team records
+// leader: base solve, then publish what the row-finishing lanes need
 template <typename T, int ROBOT, typename LDS>
-SNI void phase_team_expand(const SubCtx<T, ROBOT>& C, const LDS lds) {
+SNI void phase_base_lead(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
   using TRW = TeamRows<T, LDS>;
+  constexpr int LN = LDS::LANES;
+  Sym6<T> Lam; T qsl[4][3];
+  base_solve<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds, Lam, qsl);
+  T* bc = TRW::bc(lds.lane);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) bc[i * 6 + j] = Lam.m[i][j];
+  bc[36] = C.ub.a.x; bc[37] = C.ub.a.y; bc[38] = C.ub.a.z; bc[39] = C.ub.l.x; bc[40] = C.ub.l.y; bc[41] = C.ub.l.z;
+#pragma unroll
+  for (int L = 0; L < 4; L++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) bc[42 + L * 3 + k] = qsl[L][k];
+  T* hdr = lds.hdr();
+  hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
+}
+
+// all 16 lanes: lane t finishes rows t, t+16 and writes them as team records
+//   rec: 18 (J_c, B_c) pairs (zero for other legs' components) + 2 zero pairs;  sca: rhs, 1/diag, mu,
+//   lo-multiplier, parent-impulse byte offset;  lam: warm-start impulse
+template <typename T, int ROBOT, typename LDS>
+SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
+  using TRW = TeamRows<T, LDS>;
+  constexpr int LN = LDS::LANES;
   const int col = lds.lane;
-  const int nlt = C.nlim_total, nc = C.nc, nrows = nlt + 3 * nc, rfric = nlt + nc;
+  const T* hdr = lds.hdr();
+  const int nlt = (int)hdr[0], nc = (int)hdr[LN], nrows = nlt + 3 * nc, rfric = nlt + nc;
   T* const rec = TRW::rec(col); T* const sca = TRW::sca(col); T* const lam = TRW::lam(col);
-  lam[TRW::TR * 4] = T(1e30);
-  for (int r = 0; r <= nrows; r++) {
-    T* q = rec + r * (4 * TRW::REC);
-    T* sc = sca + r * (4 * TRW::SCA);
+  const T* bc = TRW::bc(col);
+  if (t == 0) {   // +inf slot and this env's null row
+    lam[TRW::TR * 4] = T(1e30);
+    T* q = rec + nrows * (4 * TRW::REC); T* sc = sca + nrows * (4 * TRW::SCA);
 #pragma unroll
     for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
-    if (r == nrows) {   // null row
-      sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0);
-      reinterpret_cast<int*>(sc)[4] = (TRW::TR * 4) * (int)sizeof(T);
-      lam[r * 4] = T(0);
-      break;
-    }
+    sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0);
+    reinterpret_cast<int*>(sc)[4] = (TRW::TR * 4) * (int)sizeof(T);
+    lam[nrows * 4] = T(0);
+  }
+  if (t >= nrows) return;
+  Sym6<T> Lam;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) Lam.m[i][j] = bc[i * 6 + j];
+  const SV<T> ub{{bc[36], bc[37], bc[38]}, {bc[39], bc[40], bc[41]}};
+  for (int r = t; r < nrows; r += 16) {
     T c[ROW_CORE];
     lds.load_core(r, c);
-    const int leg = (int)lds.A(r, LDS::A_YOFF) / 3;
+    const int meta = (int)lds.A(r, LDS::A_META);
+    const int leg = (meta >> 5) & 3;
+    const T* ql = bc + 42 + leg * 3;
+    SV<T> W; T rhs, dinv;
+    finish_row(c, meta, Lam, ub, ql[0], ql[1], ql[2], pp, W, rhs, dinv);
+    T* q = rec + r * (4 * TRW::REC);
+    T* sc = sca + r * (4 * TRW::SCA);
+    q[0] = c[0]; q[1] = W.a.x; q[2] = c[1]; q[3] = W.a.y; q[4] = c[2]; q[5] = W.a.z;
+    q[6] = c[3]; q[7] = W.l.x; q[8] = c[4]; q[9] = W.l.y; q[10] = c[5]; q[11] = W.l.z;
 #pragma unroll
-    for (int k = 0; k < 6; k++) { q[2 * k] = c[k]; q[2 * k + 1] = c[9 + k]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { q[2 * (6 + 3 * leg + k)] = c[6 + k]; q[2 * (6 + 3 * leg + k) + 1] = c[15 + k]; }
+    for (int k = 12; k < TRW::REC; k++) q[k] = T(0);
+    T* ql2 = q + 12 + 6 * leg;
+    ql2[0] = c[6]; ql2[1] = c[15]; ql2[2] = c[7]; ql2[3] = c[16]; ql2[4] = c[8]; ql2[5] = c[17];
     const bool fr = r >= rfric;
-    sc[0] = c[18]; sc[1] = c[19];
+    sc[0] = rhs; sc[1] = dinv;
     sc[2] = fr ? lds.A(r, LDS::A_MU) : T(1); sc[3] = fr ? T(-1) : T(0);
     const int par = fr ? nlt + ((r - rfric) >> 1) : TRW::TR;
     reinterpret_cast<int*>(sc)[4] = (par * 4) * (int)sizeof(T);
-    lam[r * 4] = lds.A(r, LDS::A_LAM);
+    lam[r * 4] = c[13];       // warm-start impulse (0 for friction / limit rows)
   }
 }
 
@@ -803,44 +861,55 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   constexpr int LN = LDS::LANES;
   const int col = lds.lane;
   T* const hdr = lds.hdr();
-  const int nrows = (int)hdr[0] + 3 * (int)hdr[LN];
+  const int nlt = (int)hdr[0], nc = (int)hdr[LN];
+  const int nrows = nlt + 3 * nc;
   int wmax = nrows;
 #pragma unroll
   for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
   // this lane's accumulator components: c0 = t, c1 = 16 + t (lanes 0,1) or the zero pair 18
   const bool two = t < 2;
   const int c1 = two ? 16 + t : 18;
-  T acc0 = t < 6 ? hdr[(2 + t) * LN] : lds.y()[(t - 6) * LN];
-  T acc1 = two ? lds.y()[(10 + t) * LN] : T(0);
   const char* const rec0 = reinterpret_cast<const char*>(TRW::rec(col)) + 2 * t * sizeof(T);
   const int d1 = 2 * (c1 - t) * (int)sizeof(T);
   const char* const sca0 = reinterpret_cast<const char*>(TRW::sca(col));
   char* const lam0 = reinterpret_cast<char*>(TRW::lam(col));
   constexpr int S_REC = 4 * TRW::REC * (int)sizeof(T), S_SCA = 4 * TRW::SCA * (int)sizeof(T), S_LAM = 4 * (int)sizeof(T);
   using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
-  struct Row { P2 jb0, jb1; T rhs, dinv, mu, lom, lam; int poff; };
+  // warm start: acc_c = sum over the normal rows of B_c * lam0   (dV = M^-1 J^T lam0)
+  T acc0 = T(0), acc1 = T(0);
+  for (int r = nlt; r < nlt + nc; r++) {
+    const T l0 = *reinterpret_cast<const T*>(lam0 + r * S_LAM);
+    acc0 += reinterpret_cast<const P2*>(rec0 + r * S_REC)->y * l0;
+    acc1 += reinterpret_cast<const P2*>(rec0 + r * S_REC + d1)->y * l0;
+  }
+  // Everything a row needs (record pair(s), scalars, its impulse, its parent's impulse) is fetched one
+  // row ahead, so no LDS latency sits on the dependent chain
+  //   J*acc -> DPP butterfly -> fma/add -> med3 -> delta -> acc += B*delta ;
+  // the only store->load hazard (a friction row whose parent is the row updated right now) is
+  // resolved by forwarding the fresh impulse in a register.
+  struct Row { P2 jb0, jb1; T rhs, dinv, hi, lo, lam, lamp; int poff, laddr; };
   auto fetch = [&](int rr, Row& R) {
     R.jb0 = *reinterpret_cast<const P2*>(rec0 + rr * S_REC);
     R.jb1 = *reinterpret_cast<const P2*>(rec0 + rr * S_REC + d1);
     const T* sc = reinterpret_cast<const T*>(sca0 + rr * S_SCA);
-    R.rhs = sc[0]; R.dinv = sc[1]; R.mu = sc[2]; R.lom = sc[3];
+    R.rhs = sc[0]; R.dinv = sc[1]; R.hi = sc[2]; R.lo = sc[3];          // (mu, lo-multiplier until resolved)
     R.poff = reinterpret_cast<const int*>(sc)[4];
-    R.lam = *reinterpret_cast<const T*>(lam0 + rr * S_LAM);
+    R.laddr = rr * S_LAM;
+    R.lam = *reinterpret_cast<const T*>(lam0 + R.laddr);
+    R.lamp = *reinterpret_cast<const T*>(lam0 + R.poff);
   };
   auto step = [&](int r, Row& R, Row& N) {
-    const int rc = r < nrows ? r : nrows;                 // past the end: this env's null row
-    const int rn = r + 1 < nrows ? r + 1 : nrows;
+    const int rn = r + 1 < nrows ? r + 1 : nrows;         // past the end: this env's null row
     fetch(rn, N);
-    const T lamp = *reinterpret_cast<const T*>(lam0 + R.poff);   // issued after the previous row's store: always fresh
     const T jdv = team_sum16(R.jb0.x * acc0 + R.jb1.x * acc1);
-    const T hi = R.mu * lamp, lo = R.lom * hi;
+    const T hi = R.hi * R.lamp, lo = R.lo * hi;
     T sum = R.lam + (R.rhs - jdv * R.dinv);
     if constexpr (sizeof(T) == 4) sum = __builtin_amdgcn_fmed3f(sum, lo, hi);
     else sum = sum < lo ? lo : (sum > hi ? hi : sum);
     const T delta = sum - R.lam;
     acc0 += R.jb0.y * delta; acc1 += R.jb1.y * delta;
-    if (t == 0) *reinterpret_cast<T*>(lam0 + rc * S_LAM) = sum;
-    N.lam = rn == rc ? sum : N.lam;                       // (only the null row can repeat; its sum is 0 anyway)
+    *reinterpret_cast<T*>(lam0 + R.laddr) = sum;          // all 16 lanes store the same value to the same word
+    N.lamp = N.poff == R.laddr ? sum : N.lamp;
   };
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
@@ -858,7 +927,8 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
 }
 
 template <typename T, int ROBOT, typename LDS>
-SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds, int t, bool lead) {
+SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds, int t, bool lead,
+                    bool valid) {
   constexpr int LN = LDS::LANES;
   using TRW = TeamRows<T, LDS>;
   if (lead) {
@@ -867,13 +937,11 @@ SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, s
     phase_leg<T, ROBOT, 1, LDS>(C, pp, lam_prev, nstride, lds);
     phase_leg<T, ROBOT, 2, LDS>(C, pp, lam_prev, nstride, lds);
     phase_leg<T, ROBOT, 3, LDS>(C, pp, lam_prev, nstride, lds);
-    phase_base<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
-    phase_team_expand<T, ROBOT, LDS>(C, lds);
-    T* hdr = lds.hdr();
-    hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
-    hdr[2 * LN] = C.w.a.x; hdr[3 * LN] = C.w.a.y; hdr[4 * LN] = C.w.a.z;
-    hdr[5 * LN] = C.w.l.x; hdr[6 * LN] = C.w.l.y; hdr[7 * LN] = C.w.l.z;
+    phase_base_lead<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+  } else if (!valid && t == 0) {   // idle team: no rows
+    lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
+  phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
   if (lead) {
     const T* hdr = lds.hdr();

@@ -285,12 +285,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #pragma unroll
       for (int j = 0; j < NQ; j++) C.tau[j] = tau[j] * sc;
       if constexpr (TEAM) {
-        if (!valid && t == 0) {   // idle team: zero rows, a null row to spin on
-          lds.hdr()[0] = T(0); lds.hdr()[EPB] = T(0);
-          SubCtx<T, ROBOT> Z; Z.nlim_total = 0; Z.nc = 0;
-          phase_team_expand<T, ROBOT, LDS>(Z, lds);
-        }
-        const int m = substep_team<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds, t, lead);
+        const int m = substep_team<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds, t, lead, valid);
         if (lead) E.mask = m;
       } else {
         E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
