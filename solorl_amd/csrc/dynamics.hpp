@@ -263,6 +263,22 @@ template <typename T, int ROBOT> struct SubCtx {
   SV<T> w; T y[4][3]; T lam_n[8];
 };
 
+// Context handles: the phases take the context through a handle so that its address space survives the
+// non-inlined call boundary -- private memory in lane mode (LDS is full there), LDS in team mode
+// (a generic reference would turn every context access into a FLAT instruction into scratch).
+template <typename T, int ROBOT> struct CtxPriv {
+  SubCtx<T, ROBOT>* p;
+  SD SubCtx<T, ROBOT>& get() const { return *p; }
+};
+#ifndef SOLO_HOST_SHIM
+template <typename T, int ROBOT, size_t OFF> struct CtxLds {
+  int col;
+  SD SubCtx<T, ROBOT>& get() const {
+    return *reinterpret_cast<SubCtx<T, ROBOT>*>(solo_smem + OFF + (size_t)col * sizeof(SubCtx<T, ROBOT>));
+  }
+};
+#endif
+
 // park one half-built row in LDS: f0 (force transmitted to the base), JL (raw joint torques),
 // Y (leg response, base fixed), the contact point P and penetration for the finishing loop.
 template <typename T, typename LDS>
@@ -281,8 +297,9 @@ SD void park_row(const LDS& lds, int slot, SV<T> f0, const T (&JL)[3], const T (
 
 // ---------------------------------------------------------------- phase 1: collision detection
 // start-of-step pose (K1, K6'): support points, contact mask, MAX_CONTACTS cap, row counts
-template <typename T, int ROBOT>
-SNI void phase_detect(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp) {
+template <typename T, int ROBOT, typename CH>
+SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
+  SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NQ = RB::NQ;
   const PhysState<T, NQ>& st = C.ps;
@@ -342,8 +359,9 @@ SNI void phase_detect(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp) {
 
 // ---------------------------------------------------------------- phase 2 (x4): one leg
 // FK + ABA passes 1-2, leg response (G, qdd0), parked limit and contact rows of this leg
-template <typename T, int ROBOT, int L, typename LDS>
-SNI void phase_leg(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+template <typename T, int ROBOT, int L, typename LDS, typename CH>
+SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+  SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   constexpr int L0 = 1 + L * (NJ + 1);
@@ -570,8 +588,9 @@ SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const S
   }
 }
 
-template <typename T, int ROBOT, typename LDS>
-SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_base(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+  SubCtx<T, ROBOT>& C = ch.get();
   constexpr int LN = LDS::LANES;
   Sym6<T> Lam; T qsl[4][3];
   base_solve<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds, Lam, qsl);
@@ -612,8 +631,9 @@ SNI void phase_base(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_p
 // impulse, friction coefficient and leg id are fetched while row r is computed; a friction row's
 // parent is found arithmetically (parent = nlim + (r - nlim - nc)/2), so there is no dependent
 // LDS chain.  Accumulators: base delta-velocity w in registers, leg delta-rates y in LDS.
-template <typename T, int ROBOT, typename LDS>
-SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const LDS lds) {
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
+  SubCtx<T, ROBOT>& C = ch.get();
   using R_ = LDS;
   using Chunk = typename R_::Chunk;
   constexpr int NCH = R_::NCH, LN = R_::LANES;
@@ -697,8 +717,9 @@ SNI void phase_pgs(SubCtx<T, ROBOT>& C, int iterations, const LDS lds) {
 
 // ---------------------------------------------------------------- phase 5: apply + integrate
 // delta-velocities (clamp K5), impulse cache, semi-implicit Euler (K1)
-template <typename T, int ROBOT, typename LDS>
-SNI void phase_integrate(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS lds) {
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_integrate(CH ch, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS lds) {
+  SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   const T dt = pp.dt;
@@ -774,7 +795,8 @@ template <typename T, typename LDS> struct TeamRows {
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
   static constexpr size_t off_bc = off_lam + (size_t)(TR + 1) * 4 * sizeof(T);
-  static constexpr size_t bytes = off_bc + (size_t)4 * BC * sizeof(T);
+  static constexpr size_t off_ctx = (off_bc + (size_t)4 * BC * sizeof(T) + 15) & ~(size_t)15;   // 4 x SubCtx (size added by the user)
+  static constexpr size_t bytes = off_ctx;
   SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + r*4*REC
   SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + r*4*SCA
   SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + r*4
@@ -782,8 +804,9 @@ template <typename T, typename LDS> struct TeamRows {
 };
 
 // leader: base solve, then publish what the row-finishing lanes need
-template <typename T, int ROBOT, typename LDS>
-SNI void phase_base_lead(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+  SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
   Sym6<T> Lam; T qsl[4][3];
@@ -926,24 +949,33 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   if (two) lds.y()[(10 + t) * LN] = acc1;
 }
 
+template <typename T, int ROBOT, typename LDS> struct TeamCtx {
+  using type = CtxLds<T, ROBOT, TeamRows<T, LDS>::off_ctx>;
+  static constexpr size_t bytes = TeamRows<T, LDS>::off_ctx + 4 * sizeof(SubCtx<T, ROBOT>);
+};
+
+// the leader's context C lives in LDS (see CtxLds); `C` is only dereferenced by leader lanes
 template <typename T, int ROBOT, typename LDS>
-SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds, int t, bool lead,
-                    bool valid) {
+SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds, int t, bool lead, bool valid) {
   constexpr int LN = LDS::LANES;
   using TRW = TeamRows<T, LDS>;
+  using CH = typename TeamCtx<T, ROBOT, LDS>::type;
+  const CH ch{lds.lane};
   if (lead) {
-    phase_detect<T, ROBOT>(C, pp);
-    phase_leg<T, ROBOT, 0, LDS>(C, pp, lam_prev, nstride, lds);
-    phase_leg<T, ROBOT, 1, LDS>(C, pp, lam_prev, nstride, lds);
-    phase_leg<T, ROBOT, 2, LDS>(C, pp, lam_prev, nstride, lds);
-    phase_leg<T, ROBOT, 3, LDS>(C, pp, lam_prev, nstride, lds);
-    phase_base_lead<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_detect<T, ROBOT, CH>(ch, pp);
+    phase_leg<T, ROBOT, 0, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 1, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 2, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 3, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+    phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   } else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
+  int mask = 0;
   if (lead) {
+    SubCtx<T, ROBOT>& C = ch.get();
     const T* hdr = lds.hdr();
     C.w.a = mk(hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]); C.w.l = mk(hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]);
 #pragma unroll
@@ -958,9 +990,10 @@ SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, s
       const int p = 12 + i;
       C.lam_n[i] = ((C.mask >> p) & 1) ? lam[(C.nlim_total + __popc(C.mask & ((1 << p) - 1))) * 4] : T(0);
     }
-    phase_integrate<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+    phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+    mask = C.mask;
   }
-  return C.mask;
+  return mask;
 }
 #endif  // !SOLO_HOST_SHIM
 
@@ -969,14 +1002,16 @@ SD int substep_team(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, s
 // warm-start impulses (global memory, stride = nstride).  Returns the contact bit mask.
 template <typename T, int ROBOT, typename LDS>
 SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds) {
-  phase_detect<T, ROBOT>(C, pp);
-  phase_leg<T, ROBOT, 0, LDS>(C, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 1, LDS>(C, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 2, LDS>(C, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 3, LDS>(C, pp, lam_prev, nstride, lds);
-  phase_base<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
-  phase_pgs<T, ROBOT, LDS>(C, pp.iterations, lds);
-  phase_integrate<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds);
+  using CH = CtxPriv<T, ROBOT>;
+  const CH ch{&C};
+  phase_detect<T, ROBOT, CH>(ch, pp);
+  phase_leg<T, ROBOT, 0, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 1, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 2, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  phase_leg<T, ROBOT, 3, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  phase_base<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, lds);
+  phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   return C.mask;
 }
 

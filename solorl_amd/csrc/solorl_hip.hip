@@ -276,7 +276,22 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       }
   }
   E.xyprev[0] = E.ps.pos.x; E.xyprev[1] = E.ps.pos.y;
-  {
+  if constexpr (TEAM) {
+    using CH = typename TeamCtx<T, ROBOT, LDS>::type;
+    const CH ch{col};
+    if (lead) ch.get().ps = E.ps;
+#pragma unroll 1
+    for (int ss = 0; ss < P.frame_skip; ss++) {
+      const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
+      if (lead) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) ch.get().tau[j] = tau[j] * sc;
+      }
+      const int m = substep_team<T, ROBOT>(pp, sf + (size_t)L.lam * N + e, (size_t)N, lds, t, lead, valid);
+      if (lead) E.mask = m;
+    }
+    if (lead) E.ps = ch.get().ps;
+  } else {
     SubCtx<T, ROBOT> C;
     C.ps = E.ps;
 #pragma unroll 1
@@ -284,12 +299,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
 #pragma unroll
       for (int j = 0; j < NQ; j++) C.tau[j] = tau[j] * sc;
-      if constexpr (TEAM) {
-        const int m = substep_team<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds, t, lead, valid);
-        if (lead) E.mask = m;
-      } else {
-        E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
-      }
+      E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
     }
     E.ps = C.ps;
   }
@@ -505,7 +515,7 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
     auto kt = step_kernel_team<T, ROBOT>;
     dim3 grid((N + 3) / 4), block(64);
     using TeamLds = RowLds<T, 4>;
-    const size_t team_smem = TeamRows<T, TeamLds>::bytes;
+    const size_t team_smem = TeamCtx<T, ROBOT, TeamLds>::bytes;
     hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
                        make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
     HIP_TRY(hipGetLastError());
