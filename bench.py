@@ -53,6 +53,31 @@ def cpu_baseline(cfg, budget_s=12.0):
             "sample": "%d Solo12-walk envs x %d control steps, random policy, OpenMP over envs (%.1f s)" % (N, steps, el)}
 
 
+def ppo_leg(env, dev, world, T):
+    """One PPO iteration with the README hyper-parameters (lr 2.5e-4, entropy 0.01, clip 0.1, GAE,
+    ppo-epoch 5 scaled to 1 epoch here, 50 mini-batches): rollout of T steps + returns + update."""
+    import torch
+    from solorl_amd.ppo import Policy, PPO, RolloutStorage
+    from solorl_amd.ppo.train import rollout
+    N = env.nenvs
+    torch.manual_seed(1)
+    pol = Policy(env.observation_space.shape, env.action_space, None, {"hidden_size": 64}).to(dev)
+    agent = PPO(pol, 0.1, 1, max(T * N // 50, 1), 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
+    st = RolloutStorage(T, N, env.observation_space.shape, env.act_dim, dev)
+    st.obs[0].copy_(env.get_observation())
+    rollout(env, pol, st, min(T, 8))            # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rollout(env, pol, st, T)
+    torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
+    with torch.no_grad():
+        nv = pol.get_value(st.obs[-1])
+    st.compute_returns(nv, True, 0.99, 0.95)
+    agent.update(st)
+    torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+    return {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
+            "ppo_epoch": 1, "mini_batches": 50, "note": "policy forward + env.step + storage per step, then GAE + one PPO epoch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ppo-steps", type=int, default=64, help="rollout length of the auxiliary PPO-loop leg (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +137,11 @@ def main():
         a.record(); env.step_inplace(acts[t % R]); b.record()
     torch.cuda.synchronize()
     kms = sorted(a.elapsed_time(b) for a, b in ev)
-    k_avg = sum(kms) / len(kms)
+    k_avg = sum(kms) / len(kms)      # one step = sort + gather + step_kernel launches; the step kernel is >95 % of it
+
+    ppo = None
+    if args.ppo_steps > 0:           # BASELINE config 3: the full PPO loop (rollout + GAE + clipped update) on the same engine
+        ppo = ppo_leg(env, dev, world, args.ppo_steps)
 
     if rank == 0:
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
@@ -128,10 +158,15 @@ def main():
                        "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "step_kernel<float,solo12,64>", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
+                         "kernel": "step_kernel_team<float,solo12> (+ sort_perm_kernel, gather_state_kernel)", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "path is FP32-VALU/latency bound (SURVEY 8d); HBM fraction is small by construction"},
         }
+        traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(traffic_file):   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            out["roofline"]["traffic"] = json.load(open(traffic_file))["bytes_per_launch"]
+        if ppo is not None:
+            out["ppo_loop"] = ppo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
