@@ -65,7 +65,12 @@ def ppo_leg(env, dev, world, T):
     agent = PPO(pol, 0.1, 1, max(T * N // 50, 1), 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
     st = RolloutStorage(T, N, env.observation_space.shape, env.act_dim, dev)
     st.obs[0].copy_(env.get_observation())
-    rollout(env, pol, st, min(T, 8))            # warm-up
+    wst = RolloutStorage(8, N, env.observation_space.shape, env.act_dim, dev)   # warm-up: rollout + one tiny update
+    wst.obs[0].copy_(env.get_observation())                                       # (first-call library initialisation)
+    rollout(env, pol, wst, 8)
+    wst.compute_returns(pol.get_value(wst.obs[-1]).detach(), True, 0.99, 0.95)
+    PPO(pol, 0.1, 1, 8 * N // 4, 0.5, 0.01, lr=1e-9, max_grad_norm=0.5).update(wst)
+    st.obs[0].copy_(env.get_observation())
     torch.cuda.synchronize(); t0 = time.perf_counter()
     rollout(env, pol, st, T)
     torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
