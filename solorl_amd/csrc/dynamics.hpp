@@ -258,6 +258,8 @@ template <typename T, int ROBOT> struct SubCtx {
   T dist[NPRIM];
   int mask, nc, nlim_total, nlim;
   ABI<T> Ibase; SV<T> pbase;
+  ABI<T> Ileg[4]; SV<T> pleg[4];   // team mode: per-leg contributions, summed by the leader
+  int limoff[4];                   // team mode: first joint-limit slot of each leg
   LegResp<T, NJ> LR[4];
   SV<T> ub; T qds[NQ];
   SV<T> w; T y[4][3]; T lam_n[8];
@@ -348,6 +350,18 @@ SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
     nl += (pp.qlim - st.q[j] < T(LIMIT_WINDOW)) ? 1 : 0;
   }
   C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
+  {
+    int run = 0;
+#pragma unroll
+    for (int L = 0; L < 4; L++) {
+      C.limoff[L] = run > MAX_LIMITS ? MAX_LIMITS : run;
+#pragma unroll
+      for (int k = 0; k < RB::NJ; k++) {
+        run += (st.q[L * RB::NJ + k] + pp.qlim < T(LIMIT_WINDOW)) ? 1 : 0;
+        run += (pp.qlim - st.q[L * RB::NJ + k] < T(LIMIT_WINDOW)) ? 1 : 0;
+      }
+    }
+  }
   // base link terms start the articulated-inertia accumulation
   constexpr solorl_link_data B = RB::MD.links[0];
   static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
@@ -508,6 +522,167 @@ SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nst
     }
   });
 }
+
+#ifndef SOLO_HOST_SHIM
+// ---------------------------------------------------------------- phase 2, team mode: the four legs in parallel
+// Lane L (0..3) of a team processes leg L.  The legs are mirror images, so the code is the same and
+// only constants differ: they are picked per lane from the four legs' compile-time values
+// (identical values fold away).  Results go to the shared (LDS) context: per-leg articulated inertia /
+// bias contributions (summed by the leader), leg response, parked rows.
+template <typename T> SD T sel4(int L, double a, double b, double c, double d) {
+  if (a == b && b == c && c == d) return T(a);
+  return L == 0 ? T(a) : (L == 1 ? T(b) : (L == 2 ? T(c) : T(d)));
+}
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds, int L) {
+  SubCtx<T, ROBOT>& C = ch.get();
+  using RB = Robot<ROBOT>;
+  constexpr int NJ = RB::NJ;
+  constexpr int ST = NJ + 1;   // links per leg
+  const T kd = pp.damping;
+  const M3<T> R0 = C.R0;
+  SV<T> vp{C.ps.w, C.ps.v};
+  T sn[NJ], cs[NJ], qd[NJ], q[NJ], tau[NJ];
+#pragma unroll
+  for (int k = 0; k < NJ; k++) {
+    sn[k] = C.sn[L * NJ + k]; cs[k] = C.cs[L * NJ + k]; qd[k] = C.ps.qd[L * NJ + k]; q[k] = C.ps.q[L * NJ + k];
+    tau[k] = C.tau[L * NJ + k];
+  }
+  // value of link field f of joint k (or the foot, k = NJ) for this lane's leg
+#define LEGC(k, f) sel4<T>(L, RB::MD.links[1 + 0 * ST + (k)].f, RB::MD.links[1 + 1 * ST + (k)].f, \
+                           RB::MD.links[1 + 2 * ST + (k)].f, RB::MD.links[1 + 3 * ST + (k)].f)
+  RBI<T> Ik[NJ]; SV<T> pk[NJ]; SV<T> Sk[NJ], ck[NJ];
+  {
+    M3<T> Rp = R0;
+    V3<T> op = mk(T(0), T(0), T(0));
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int AX = RB::MD.links[1 + k].axis[0] != 0.0 ? 0 : 1;   // same for all legs
+      V3<T> o = op + mul(Rp, mk(LEGC(k, jorigin[0]), LEGC(k, jorigin[1]), LEGC(k, jorigin[2])));
+      V3<T> a = AX == 0 ? Rp.c0 : Rp.c1;
+      M3<T> R = rot_axis<AX>(Rp, cs[k], sn[k]);
+      SV<T> S{a, cross(o, a)};
+      SV<T> vj = S * qd[k];
+      SV<T> v = vp + vj;
+      Sk[k] = S; ck[k] = crm(vp, vj);
+      V3<T> cw = o + mul(R, mk(LEGC(k, com[0]), LEGC(k, com[1]), LEGC(k, com[2])));
+      link_terms(R, cw, LEGC(k, mass), LEGC(k, inertia_box[0]), LEGC(k, inertia_box[1]), LEGC(k, inertia_box[2]), v, kd, Ik[k], pk[k]);
+      if constexpr (k == NJ - 1) {  // foot: fixed child of the last link, same axes and velocity
+        V3<T> of = o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2])));
+        V3<T> cf = of + mul(R, mk(LEGC(NJ, com[0]), LEGC(NJ, com[1]), LEGC(NJ, com[2])));
+        RBI<T> If; SV<T> pf;
+        link_terms(R, cf, LEGC(NJ, mass), LEGC(NJ, inertia_box[0]), LEGC(NJ, inertia_box[1]), LEGC(NJ, inertia_box[2]), v, kd, If, pf);
+        add(Ik[k], If); pk[k] = pk[k] + pf;
+      }
+      Rp = R; op = o; vp = v;
+    });
+  }
+#undef LEGC
+  // pass 2: outermost joint first
+  SV<T> Uk[NJ]; T Dk[NJ], uk[NJ];
+  {
+    ABI<T> IA = to_abi(Ik[NJ - 1]);
+    SV<T> pA = pk[NJ - 1];
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = NJ - 1 - decltype(kc)::value;
+      SV<T> S = Sk[k];
+      SV<T> U = mul(IA, S);
+      T Dinv = T(1) / dot(S, U);
+      T u = tau[k] - dot(S, pA);
+      Uk[k] = U; Dk[k] = Dinv; uk[k] = u;
+      rank1_sub(IA, U, Dinv);
+      SV<T> pa = pA + mul(IA, ck[k]) + U * (u * Dinv);
+      if constexpr (k > 0) { add(IA, Ik[k - 1]); pA = pk[k - 1] + pa; }
+      else { C.Ileg[L] = IA; C.pleg[L] = pa; }
+    });
+  }
+  LegResp<T, NJ> LR;
+  {
+    SV<T> ap = zero6<T>();
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      SV<T> apc = ap + ck[k];
+      T qdd = (uk[k] - dot(Uk[k], apc)) * Dk[k];
+      LR.qdd0[k] = qdd;
+      if constexpr (k < NJ - 1) ap = fma6(Sk[k], qdd, apc);
+    });
+  }
+  T Minv[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Minv[i][j] = T(0);
+  static_for<NJ>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T t[NJ];
+    SV<T> f = Uk[j] * (-Dk[j]);
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = NJ - 1 - decltype(kc)::value;
+      if constexpr (k > j) t[k] = T(0);
+      else if constexpr (k == j) t[k] = T(1);
+      else { t[k] = dot(Sk[k], f); f = fma6(Uk[k], -t[k] * Dk[k], f); }
+    });
+    LR.G[j] = f * T(-1);
+    SV<T> dv = zero6<T>();
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      T yk;
+      if constexpr (k == 0) yk = t[0] * Dk[0]; else yk = (t[k] - dot(Uk[k], dv)) * Dk[k];
+      Minv[k][j] = yk;
+      if constexpr (k < NJ - 1) dv = fma6(Sk[k], yk, dv);
+    });
+  });
+  C.LR[L] = LR;
+  // joint-limit rows of this leg: slots from the per-leg offsets of phase_detect
+  int nlim = C.limoff[L];
+  static_for<NJ>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
+      if (pen < T(LIMIT_WINDOW) && nlim < MAX_LIMITS) {
+        T sg = side == 0 ? T(1) : T(-1);
+        T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
+        JL[k] = sg;
+        park_row(lds, nlim, LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
+        nlim++;
+      }
+    }
+  });
+  // contact rows of this leg's primitives: knee (chain depth NJ-1) and foot (depth NJ)
+  const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
+  static_for<2>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int DEPTH = i == 0 ? NJ - 1 : NJ;
+    const int p = 12 + 2 * L + i;
+    if ((mask >> p) & 1) {
+      const int cidx = __popc(mask & ((1 << p) - 1));
+      const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
+      const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
+      const T pen = C.dist[p] + pp.slop;
+      const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
+      const T fric = sel4<T>(L, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
+                             RB::MD.prims[18 + i].friction);
+      static_for<3>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
+        SV<T> F{cross(P, u), u};
+        T JL[3] = {T(0), T(0), T(0)}, Y[3];
+        SV<T> f0 = F;
+        static_for<DEPTH>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          JL[k] = dot(Sk[k], F);
+          f0 = fma6(LR.G[k], -JL[k], f0);
+        });
+#pragma unroll
+        for (int r = 0; r < 3; r++) Y[r] = Minv[r][0] * JL[0] + Minv[r][1] * JL[1] + Minv[r][2] * JL[2];
+        park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0), fric,
+                 (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8));
+      });
+    }
+  });
+}
+#endif  // !SOLO_HOST_SHIM
 
 // ---------------------------------------------------------------- phase 3: base solve + finish rows
 // base_solve: parks the base primitives' rows, inverts the base articulated inertia, computes the
@@ -809,6 +984,12 @@ SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size
   SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
+  {   // base articulated inertia / bias = base link + the four legs' contributions (phase_leg_rt)
+    ABI<T> Ib = C.Ibase; SV<T> pb = C.pbase;
+#pragma unroll
+    for (int L = 0; L < 4; L++) { add(Ib, C.Ileg[L]); pb = pb + C.pleg[L]; }
+    C.Ibase = Ib; C.pbase = pb;
+  }
   Sym6<T> Lam; T qsl[4][3];
   base_solve<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds, Lam, qsl);
   T* bc = TRW::bc(lds.lane);
@@ -961,14 +1142,10 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
   using TRW = TeamRows<T, LDS>;
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
   const CH ch{lds.lane};
-  if (lead) {
-    phase_detect<T, ROBOT, CH>(ch, pp);
-    phase_leg<T, ROBOT, 0, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-    phase_leg<T, ROBOT, 1, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-    phase_leg<T, ROBOT, 2, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-    phase_leg<T, ROBOT, 3, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-    phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  } else if (!valid && t == 0) {   // idle team: no rows
+  if (lead) phase_detect<T, ROBOT, CH>(ch, pp);
+  if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);   // four legs on four lanes
+  if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
