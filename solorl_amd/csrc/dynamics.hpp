@@ -1023,7 +1023,7 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
     T* q = rec + nrows * (4 * TRW::REC); T* sc = sca + nrows * (4 * TRW::SCA);
 #pragma unroll
     for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
-    sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0);
+    sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0); sc[5] = T(0);
     reinterpret_cast<int*>(sc)[4] = (TRW::TR * 4) * (int)sizeof(T);
     lam[nrows * 4] = T(0);
   }
@@ -1059,6 +1059,28 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
   }
 }
 
+// coupling of the row pairs (2m, 2m+1) swept together: c_m = J_{2m+1} . B_{2m}   (lane m computes pair m)
+template <typename T, typename LDS>
+SNI void phase_pair_coupling(const LDS lds, int t) {
+  using TRW = TeamRows<T, LDS>;
+  constexpr int LN = LDS::LANES;
+  const int col = lds.lane;
+  const T* hdr = lds.hdr();
+  const int nrows = (int)hdr[0] + 3 * (int)hdr[LN];
+  if (2 * t >= nrows) return;
+  const T* r0 = TRW::rec(col) + (2 * t) * (4 * TRW::REC);
+  const T* r1 = r0 + 4 * TRW::REC;
+  T c = T(0);
+#pragma unroll
+  for (int k = 0; k < 18; k++) c += r1[2 * k] * r0[2 * k + 1];
+  TRW::sca(col)[(2 * t + 1) * (4 * TRW::SCA) + 5] = c;
+}
+
+// Pair sweep: rows 2m and 2m+1 are updated in one step.  Each 8-lane half of the DPP row holds a
+// full copy of the 18 accumulator components (3 per lane); half 0 reduces row 2m's dot product and
+// half 1 row 2m+1's AT THE SAME TIME against the pre-update accumulators; the Gauss-Seidel dependency
+// is restored analytically:  J_{2m+1}.(acc + B_{2m} d0) = J_{2m+1}.acc + c_m d0.  This is a
+// re-association of the same sums (parity bounds unchanged).
 template <typename T, int ROBOT, typename LDS>
 SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
@@ -1070,64 +1092,89 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   int wmax = nrows;
 #pragma unroll
   for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
-  // this lane's accumulator components: c0 = t, c1 = 16 + t (lanes 0,1) or the zero pair 18
-  const bool two = t < 2;
-  const int c1 = two ? 16 + t : 18;
-  const char* const rec0 = reinterpret_cast<const char*>(TRW::rec(col)) + 2 * t * sizeof(T);
-  const int d1 = 2 * (c1 - t) * (int)sizeof(T);
+  const int h = t & 7, half = t >> 3;
+  // accumulator components of this lane: h, h+8 and (h < 2) 16+h, else the zero pair 18
+  const int cc = h < 2 ? 16 + h : 18;
+  const char* const recA = reinterpret_cast<const char*>(TRW::rec(col)) + 2 * h * sizeof(T);
+  constexpr int dB = 2 * 8 * (int)sizeof(T);
+  const int dC = 2 * (cc - h) * (int)sizeof(T);
   const char* const sca0 = reinterpret_cast<const char*>(TRW::sca(col));
   char* const lam0 = reinterpret_cast<char*>(TRW::lam(col));
   constexpr int S_REC = 4 * TRW::REC * (int)sizeof(T), S_SCA = 4 * TRW::SCA * (int)sizeof(T), S_LAM = 4 * (int)sizeof(T);
   using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
   // warm start: acc_c = sum over the normal rows of B_c * lam0   (dV = M^-1 J^T lam0)
-  T acc0 = T(0), acc1 = T(0);
+  T a0 = T(0), a1 = T(0), a2 = T(0);
   for (int r = nlt; r < nlt + nc; r++) {
     const T l0 = *reinterpret_cast<const T*>(lam0 + r * S_LAM);
-    acc0 += reinterpret_cast<const P2*>(rec0 + r * S_REC)->y * l0;
-    acc1 += reinterpret_cast<const P2*>(rec0 + r * S_REC + d1)->y * l0;
+    a0 += reinterpret_cast<const P2*>(recA + r * S_REC)->y * l0;
+    a1 += reinterpret_cast<const P2*>(recA + r * S_REC + dB)->y * l0;
+    a2 += reinterpret_cast<const P2*>(recA + r * S_REC + dC)->y * l0;
   }
-  // Everything a row needs (record pair(s), scalars, its impulse, its parent's impulse) is fetched one
-  // row ahead, so no LDS latency sits on the dependent chain
-  //   J*acc -> DPP butterfly -> fma/add -> med3 -> delta -> acc += B*delta ;
-  // the only store->load hazard (a friction row whose parent is the row updated right now) is
-  // resolved by forwarding the fresh impulse in a register.
-  struct Row { P2 jb0, jb1; T rhs, dinv, hi, lo, lam, lamp; int poff, laddr; };
-  auto fetch = [&](int rr, Row& R) {
-    R.jb0 = *reinterpret_cast<const P2*>(rec0 + rr * S_REC);
-    R.jb1 = *reinterpret_cast<const P2*>(rec0 + rr * S_REC + d1);
-    const T* sc = reinterpret_cast<const T*>(sca0 + rr * S_SCA);
-    R.rhs = sc[0]; R.dinv = sc[1]; R.hi = sc[2]; R.lo = sc[3];          // (mu, lo-multiplier until resolved)
-    R.poff = reinterpret_cast<const int*>(sc)[4];
-    R.laddr = rr * S_LAM;
-    R.lam = *reinterpret_cast<const T*>(lam0 + R.laddr);
-    R.lamp = *reinterpret_cast<const T*>(lam0 + R.poff);
+  // per pair: own = the row this half reduces (2m + half), oth = the other one
+  struct Pair { P2 o0, o1, o2, x0, x1, x2; T rhs0, dinv0, mu0, lom0, rhs1, dinv1, mu1, lom1, cpl, lam0, lam1; int p0, p1, la0, la1; };
+  auto fetch = [&](int r0, Pair& R) {          // r0 = first row of the pair (already clamped to the null row)
+    const int r1 = r0 + 1 <= nrows ? r0 + 1 : nrows;
+    const int ro = half ? r1 : r0, rx = half ? r0 : r1;
+    const char* po = recA + ro * S_REC; const char* px = recA + rx * S_REC;
+    R.o0 = *reinterpret_cast<const P2*>(po); R.o1 = *reinterpret_cast<const P2*>(po + dB); R.o2 = *reinterpret_cast<const P2*>(po + dC);
+    R.x0 = *reinterpret_cast<const P2*>(px); R.x1 = *reinterpret_cast<const P2*>(px + dB); R.x2 = *reinterpret_cast<const P2*>(px + dC);
+    const T* s0 = reinterpret_cast<const T*>(sca0 + r0 * S_SCA); const T* s1 = reinterpret_cast<const T*>(sca0 + r1 * S_SCA);
+    R.rhs0 = s0[0]; R.dinv0 = s0[1]; R.mu0 = s0[2]; R.lom0 = s0[3]; R.p0 = reinterpret_cast<const int*>(s0)[4];
+    R.rhs1 = s1[0]; R.dinv1 = s1[1]; R.mu1 = s1[2]; R.lom1 = s1[3]; R.p1 = reinterpret_cast<const int*>(s1)[4]; R.cpl = s1[5];
+    R.la0 = r0 * S_LAM; R.la1 = r1 * S_LAM;
+    R.lam0 = *reinterpret_cast<const T*>(lam0 + R.la0);
+    R.lam1 = *reinterpret_cast<const T*>(lam0 + R.la1);
   };
-  auto step = [&](int r, Row& R, Row& N) {
-    const int rn = r + 1 < nrows ? r + 1 : nrows;         // past the end: this env's null row
-    fetch(rn, N);
-    const T jdv = team_sum16(R.jb0.x * acc0 + R.jb1.x * acc1);
-    const T hi = R.hi * R.lamp, lo = R.lo * hi;
-    T sum = R.lam + (R.rhs - jdv * R.dinv);
-    if constexpr (sizeof(T) == 4) sum = __builtin_amdgcn_fmed3f(sum, lo, hi);
-    else sum = sum < lo ? lo : (sum > hi ? hi : sum);
-    const T delta = sum - R.lam;
-    acc0 += R.jb0.y * delta; acc1 += R.jb1.y * delta;
-    *reinterpret_cast<T*>(lam0 + R.laddr) = sum;          // all 16 lanes store the same value to the same word
-    N.lamp = N.poff == R.laddr ? sum : N.lamp;
+  auto step = [&](int r, Pair& R, Pair& N) {
+    // parents' impulses first (fresh: issued after the previous pair's stores), then the next pair's prefetch
+    const T lp0 = *reinterpret_cast<const T*>(lam0 + R.p0);
+    const T lp1r = *reinterpret_cast<const T*>(lam0 + R.p1);
+    const int rnext = r + 2 < nrows ? r + 2 : nrows;
+    fetch(rnext, N);
+    T d = R.o0.x * a0 + R.o1.x * a1 + R.o2.x * a2;   // 8-lane butterfly: both halves reduce their own row at once
+    if constexpr (sizeof(T) == 4) {
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
+    } else { d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16); }
+    T dx;            // the other half's dot product (row_mirror: lane i <-> 15 - i)
+    if constexpr (sizeof(T) == 4) dx = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
+    else dx = __shfl_xor(d, 8, 16);
+    const T d0 = half ? dx : d, d1 = half ? d : dx;
+    // row 2m
+    const T hi0 = R.mu0 * lp0, lo0 = R.lom0 * hi0;
+    T s0 = R.lam0 + (R.rhs0 - d0 * R.dinv0);
+    if constexpr (sizeof(T) == 4) s0 = __builtin_amdgcn_fmed3f(s0, lo0, hi0); else s0 = s0 < lo0 ? lo0 : (s0 > hi0 ? hi0 : s0);
+    const T del0 = s0 - R.lam0;
+    // row 2m+1 sees row 2m's update through the coupling; its parent may be row 2m
+    const T lp1 = R.p1 == R.la0 ? s0 : lp1r;
+    const T hi1 = R.mu1 * lp1, lo1 = R.lom1 * hi1;
+    T s1 = R.lam1 + (R.rhs1 - (d1 + R.cpl * del0) * R.dinv1);
+    if constexpr (sizeof(T) == 4) s1 = __builtin_amdgcn_fmed3f(s1, lo1, hi1); else s1 = s1 < lo1 ? lo1 : (s1 > hi1 ? hi1 : s1);
+    const T del1 = s1 - R.lam1;
+    const T dself = half ? del1 : del0, doth = half ? del0 : del1;
+    a0 += R.o0.y * dself + R.x0.y * doth;
+    a1 += R.o1.y * dself + R.x1.y * doth;
+    a2 += R.o2.y * dself + R.x2.y * doth;
+    *reinterpret_cast<T*>(lam0 + R.la0) = s0;
+    *reinterpret_cast<T*>(lam0 + R.la1) = s1;     // (la1 == la0 only on the null row, where s0 == s1 == 0)
   };
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
-    Row A, B;
+    Pair A, B;
     fetch(0, A);
 #pragma unroll 1
-    for (int r = 0; r < wmax; r += 2) {
-      step(r, A, B);
-      step(r + 1, B, A);
+    for (int r = 0; r < wmax; r += 4) {
+      step(r < nrows ? r : nrows, A, B);
+      step(r + 2 < nrows ? r + 2 : nrows, B, A);
     }
   }
-  // accumulators back to LDS for the leader
-  if (t < 6) hdr[(2 + t) * LN] = acc0; else lds.y()[(t - 6) * LN] = acc0;
-  if (two) lds.y()[(10 + t) * LN] = acc1;
+  // accumulators back to LDS for the leader (half 0 holds the same values as half 1)
+  if (half == 0) {
+    if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0;
+    lds.y()[(h + 2) * LN] = a1;
+    if (h < 2) lds.y()[(10 + h) * LN] = a2;
+  }
 }
 
 template <typename T, int ROBOT, typename LDS> struct TeamCtx {
@@ -1149,6 +1196,7 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
+  phase_pair_coupling<T, LDS>(lds, t);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
   int mask = 0;
   if (lead) {
