@@ -965,7 +965,8 @@ template <typename T> SD T team_sum16(T x) {
 // TR = MAX_ROWS + 1: row `nrows` of every env is a null row, so teams with fewer rows than the wave
 // maximum spin on it instead of needing liveness selects.
 template <typename T, typename LDS> struct TeamRows {
-  static constexpr int TR = MAX_ROWS + 1, REC = 40, SCA = 8, BC = 56;
+  static constexpr int TR = MAX_ROWS + 4, REC = 38, SCA = 8, BC = 56;   // + null/padding rows up to the wave maximum (a prefetch
+                                                                       // overrun of one pair lands in the following arrays: harmless)
   static constexpr size_t off_rec = LDS::bytes(4);
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
@@ -1018,14 +1019,20 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
   const int nlt = (int)hdr[0], nc = (int)hdr[LN], nrows = nlt + 3 * nc, rfric = nlt + nc;
   T* const rec = TRW::rec(col); T* const sca = TRW::sca(col); T* const lam = TRW::lam(col);
   const T* bc = TRW::bc(col);
-  if (t == 0) {   // +inf slot and this env's null row
-    lam[TRW::TR * 4] = T(1e30);
-    T* q = rec + nrows * (4 * TRW::REC); T* sc = sca + nrows * (4 * TRW::SCA);
+  // null rows from this env's row count up to the (even) wave maximum + 4: the sweep then runs every
+  // team over the same row range with no clamping, and its prefetch may overrun by one pair
+  int wmax = nrows;
+#pragma unroll
+  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
+  const int wpad = ((wmax + 1) & ~1) + 4;
+  if (t == 0) lam[TRW::TR * 4] = T(1e30);
+  for (int r = nrows + t; r < wpad; r += 16) {
+    T* q = rec + r * (4 * TRW::REC); T* sc = sca + r * (4 * TRW::SCA);
 #pragma unroll
     for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
     sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0); sc[5] = T(0);
-    reinterpret_cast<int*>(sc)[4] = (TRW::TR * 4) * (int)sizeof(T);
-    lam[nrows * 4] = T(0);
+    *reinterpret_cast<int*>(&sc[4]) = (TRW::TR * 4) * (int)sizeof(T);
+    lam[r * 4] = T(0);
   }
   if (t >= nrows) return;
   Sym6<T> Lam;
@@ -1054,7 +1061,7 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
     sc[0] = rhs; sc[1] = dinv;
     sc[2] = fr ? lds.A(r, LDS::A_MU) : T(1); sc[3] = fr ? T(-1) : T(0);
     const int par = fr ? nlt + ((r - rfric) >> 1) : TRW::TR;
-    reinterpret_cast<int*>(sc)[4] = (par * 4) * (int)sizeof(T);
+    *reinterpret_cast<int*>(&sc[4]) = (par * 4) * (int)sizeof(T);
     lam[r * 4] = c[13];       // warm-start impulse (0 for friction / limit rows)
   }
 }
@@ -1080,7 +1087,9 @@ SNI void phase_pair_coupling(const LDS lds, int t) {
 // full copy of the 18 accumulator components (3 per lane); half 0 reduces row 2m's dot product and
 // half 1 row 2m+1's AT THE SAME TIME against the pre-update accumulators; the Gauss-Seidel dependency
 // is restored analytically:  J_{2m+1}.(acc + B_{2m} d0) = J_{2m+1}.acc + c_m d0.  This is a
-// re-association of the same sums (parity bounds unchanged).
+// re-association of the same sums (parity bounds unchanged).  Every team's rows are padded with null
+// rows to the wave maximum, so the loop has no clamps and all LDS accesses are running 32-bit byte
+// offsets with immediate displacements.
 template <typename T, int ROBOT, typename LDS>
 SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
@@ -1092,81 +1101,83 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   int wmax = nrows;
 #pragma unroll
   for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
+  const int npairs2 = (wmax + 3) >> 2;          // loop trips: two pairs per trip
   const int h = t & 7, half = t >> 3;
-  // accumulator components of this lane: h, h+8 and (h < 2) 16+h, else the zero pair 18
-  const int cc = h < 2 ? 16 + h : 18;
-  const char* const recA = reinterpret_cast<const char*>(TRW::rec(col)) + 2 * h * sizeof(T);
-  constexpr int dB = 2 * 8 * (int)sizeof(T);
-  const int dC = 2 * (cc - h) * (int)sizeof(T);
-  const char* const sca0 = reinterpret_cast<const char*>(TRW::sca(col));
-  char* const lam0 = reinterpret_cast<char*>(TRW::lam(col));
-  constexpr int S_REC = 4 * TRW::REC * (int)sizeof(T), S_SCA = 4 * TRW::SCA * (int)sizeof(T), S_LAM = 4 * (int)sizeof(T);
+  const int cc = h < 2 ? 16 + h : 18;           // third accumulator component (or the zero pair)
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int S_REC = 4 * TRW::REC * SZ, S_SCA = 4 * TRW::SCA * SZ, S_LAM = 4 * SZ;
+  constexpr int dB = 2 * 8 * SZ;
+  const int dC = 2 * (cc - h) * SZ;
   using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+  using P4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
+  auto ldT = [&](int off) -> T { return *reinterpret_cast<const T*>(solo_smem + off); };
+  auto ldI = [&](int off) -> int { return *reinterpret_cast<const int*>(solo_smem + off); };
+  auto ld2 = [&](int off) -> P2 { return *reinterpret_cast<const P2*>(solo_smem + off); };
+  auto ld4 = [&](int off) -> P4 { return *reinterpret_cast<const P4*>(solo_smem + off); };
+  const int rec0 = (int)TRW::off_rec + (col * TRW::REC + 2 * h) * SZ;     // pair h of row 0
+  const int sca0 = (int)TRW::off_sca + col * TRW::SCA * SZ;
+  const int lam0 = (int)TRW::off_lam + col * SZ;
   // warm start: acc_c = sum over the normal rows of B_c * lam0   (dV = M^-1 J^T lam0)
   T a0 = T(0), a1 = T(0), a2 = T(0);
   for (int r = nlt; r < nlt + nc; r++) {
-    const T l0 = *reinterpret_cast<const T*>(lam0 + r * S_LAM);
-    a0 += reinterpret_cast<const P2*>(recA + r * S_REC)->y * l0;
-    a1 += reinterpret_cast<const P2*>(recA + r * S_REC + dB)->y * l0;
-    a2 += reinterpret_cast<const P2*>(recA + r * S_REC + dC)->y * l0;
+    const T l0 = ldT(lam0 + r * S_LAM);
+    a0 += ld2(rec0 + r * S_REC).y * l0; a1 += ld2(rec0 + r * S_REC + dB).y * l0; a2 += ld2(rec0 + r * S_REC + dC).y * l0;
   }
-  // per pair: own = the row this half reduces (2m + half), oth = the other one
-  struct Pair { P2 o0, o1, o2, x0, x1, x2; T rhs0, dinv0, mu0, lom0, rhs1, dinv1, mu1, lom1, cpl, lam0, lam1; int p0, p1, la0, la1; };
-  auto fetch = [&](int r0, Pair& R) {          // r0 = first row of the pair (already clamped to the null row)
-    const int r1 = r0 + 1 <= nrows ? r0 + 1 : nrows;
-    const int ro = half ? r1 : r0, rx = half ? r0 : r1;
-    const char* po = recA + ro * S_REC; const char* px = recA + rx * S_REC;
-    R.o0 = *reinterpret_cast<const P2*>(po); R.o1 = *reinterpret_cast<const P2*>(po + dB); R.o2 = *reinterpret_cast<const P2*>(po + dC);
-    R.x0 = *reinterpret_cast<const P2*>(px); R.x1 = *reinterpret_cast<const P2*>(px + dB); R.x2 = *reinterpret_cast<const P2*>(px + dC);
-    const T* s0 = reinterpret_cast<const T*>(sca0 + r0 * S_SCA); const T* s1 = reinterpret_cast<const T*>(sca0 + r1 * S_SCA);
-    R.rhs0 = s0[0]; R.dinv0 = s0[1]; R.mu0 = s0[2]; R.lom0 = s0[3]; R.p0 = reinterpret_cast<const int*>(s0)[4];
-    R.rhs1 = s1[0]; R.dinv1 = s1[1]; R.mu1 = s1[2]; R.lom1 = s1[3]; R.p1 = reinterpret_cast<const int*>(s1)[4]; R.cpl = s1[5];
-    R.la0 = r0 * S_LAM; R.la1 = r1 * S_LAM;
-    R.lam0 = *reinterpret_cast<const T*>(lam0 + R.la0);
-    R.lam1 = *reinterpret_cast<const T*>(lam0 + R.la1);
+  struct Pair { P2 o0, o1, o2, x0, x1, x2; P4 sA, sB; int p0, p1; T cpl, lam0, lam1; };
+  // own = the row this half reduces (2m + half), other = its partner
+  auto fetch = [&](int own, int oth, int sc, int la, Pair& R) {
+    R.o0 = ld2(own); R.o1 = ld2(own + dB); R.o2 = ld2(own + dC);
+    R.x0 = ld2(oth); R.x1 = ld2(oth + dB); R.x2 = ld2(oth + dC);
+    R.sA = ld4(sc); R.p0 = ldI(sc + 4 * SZ);
+    R.sB = ld4(sc + S_SCA); R.p1 = ldI(sc + S_SCA + 4 * SZ); R.cpl = ldT(sc + S_SCA + 5 * SZ);
+    R.lam0 = ldT(la); R.lam1 = ldT(la + S_LAM);
   };
-  auto step = [&](int r, Pair& R, Pair& N) {
-    // parents' impulses first (fresh: issued after the previous pair's stores), then the next pair's prefetch
-    const T lp0 = *reinterpret_cast<const T*>(lam0 + R.p0);
-    const T lp1r = *reinterpret_cast<const T*>(lam0 + R.p1);
-    const int rnext = r + 2 < nrows ? r + 2 : nrows;
-    fetch(rnext, N);
+  auto step = [&](int la, Pair& R) {
+    const T lp0 = ldT(lam0 + R.p0);              // parents' impulses: issued after the previous pair's stores -> fresh
+    const T lp1r = ldT(lam0 + R.p1);
     T d = R.o0.x * a0 + R.o1.x * a1 + R.o2.x * a2;   // 8-lane butterfly: both halves reduce their own row at once
+    T dx;
     if constexpr (sizeof(T) == 4) {
       d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
       d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
       d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
-    } else { d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16); }
-    T dx;            // the other half's dot product (row_mirror: lane i <-> 15 - i)
-    if constexpr (sizeof(T) == 4) dx = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
-    else dx = __shfl_xor(d, 8, 16);
+      dx = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));   // row_mirror: other half
+    } else {
+      d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16);
+      dx = __shfl_xor(d, 8, 16);
+    }
     const T d0 = half ? dx : d, d1 = half ? d : dx;
-    // row 2m
-    const T hi0 = R.mu0 * lp0, lo0 = R.lom0 * hi0;
-    T s0 = R.lam0 + (R.rhs0 - d0 * R.dinv0);
+    // row 2m:  sA = rhs, 1/diag, mu, lo-multiplier
+    const T hi0 = R.sA.z * lp0, lo0 = R.sA.w * hi0;
+    T s0 = R.lam0 + (R.sA.x - d0 * R.sA.y);
     if constexpr (sizeof(T) == 4) s0 = __builtin_amdgcn_fmed3f(s0, lo0, hi0); else s0 = s0 < lo0 ? lo0 : (s0 > hi0 ? hi0 : s0);
     const T del0 = s0 - R.lam0;
     // row 2m+1 sees row 2m's update through the coupling; its parent may be row 2m
-    const T lp1 = R.p1 == R.la0 ? s0 : lp1r;
-    const T hi1 = R.mu1 * lp1, lo1 = R.lom1 * hi1;
-    T s1 = R.lam1 + (R.rhs1 - (d1 + R.cpl * del0) * R.dinv1);
+    const T lp1 = (lam0 + R.p1) == la ? s0 : lp1r;
+    const T hi1 = R.sB.z * lp1, lo1 = R.sB.w * hi1;
+    T s1 = R.lam1 + (R.sB.x - (d1 + R.cpl * del0) * R.sB.y);
     if constexpr (sizeof(T) == 4) s1 = __builtin_amdgcn_fmed3f(s1, lo1, hi1); else s1 = s1 < lo1 ? lo1 : (s1 > hi1 ? hi1 : s1);
     const T del1 = s1 - R.lam1;
     const T dself = half ? del1 : del0, doth = half ? del0 : del1;
     a0 += R.o0.y * dself + R.x0.y * doth;
     a1 += R.o1.y * dself + R.x1.y * doth;
     a2 += R.o2.y * dself + R.x2.y * doth;
-    *reinterpret_cast<T*>(lam0 + R.la0) = s0;
-    *reinterpret_cast<T*>(lam0 + R.la1) = s1;     // (la1 == la0 only on the null row, where s0 == s1 == 0)
+    *reinterpret_cast<T*>(solo_smem + la) = s0;
+    *reinterpret_cast<T*>(solo_smem + la + S_LAM) = s1;
   };
+  const int own0 = rec0 + half * S_REC, oth0 = rec0 + (1 - half) * S_REC;
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
     Pair A, B;
-    fetch(0, A);
+    int own = own0, oth = oth0, sc = sca0, la = lam0;
+    fetch(own, oth, sc, la, A);
 #pragma unroll 1
-    for (int r = 0; r < wmax; r += 4) {
-      step(r < nrows ? r : nrows, A, B);
-      step(r + 2 < nrows ? r + 2 : nrows, B, A);
+    for (int k = 0; k < npairs2; k++) {
+      fetch(own + 2 * S_REC, oth + 2 * S_REC, sc + 2 * S_SCA, la + 2 * S_LAM, B);
+      step(la, A);
+      fetch(own + 4 * S_REC, oth + 4 * S_REC, sc + 4 * S_SCA, la + 4 * S_LAM, A);
+      step(la + 2 * S_LAM, B);
+      own += 4 * S_REC; oth += 4 * S_REC; sc += 4 * S_SCA; la += 4 * S_LAM;
     }
   }
   // accumulators back to LDS for the leader (half 0 holds the same values as half 1)
