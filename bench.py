@@ -36,7 +36,11 @@ def cpu_baseline(cfg, budget_s=12.0):
     """Oracle (fp64 CPU restatement, kind 'port') on a bounded sample of the same workload."""
     import numpy as np
     from oracle.oracle_py import Oracle
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))      # the GPU box grants a CPU share, not the whole host
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("SOLORL_CPU_THREADS", "64")))
     N = 16 * cores
     orc = Oracle(cfg, N, seed=1, threads=cores)
     orc.reset()
@@ -163,7 +167,7 @@ def main():
                        "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "step_kernel_team<float,solo12> (+ sort_perm_kernel, gather_state_kernel)", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
+                         "kernel": "step_kernel_team<float,solo12>", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "path is FP32-VALU/latency bound (SURVEY 8d); HBM fraction is small by construction"},
         }

@@ -429,8 +429,8 @@ __global__ void copy_env_kernel(const T* sf, const int* si, int N, int src, T* d
 // last contact count: a stable counting sort (9 buckets, one workgroup) yields perm[dst] = src and a
 // gather kernel moves every state field (coalesced writes).  Lanes are independent, so the
 // permutation never changes results -- only which envs share a wavefront.
-__global__ void __launch_bounds__(1024) sort_perm_kernel(const int* __restrict__ si, int N, int* __restrict__ perm) {
-  __shared__ int cnt[1024][9];
+__global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ si, int N, int* __restrict__ perm) {
+  __shared__ int cnt[256][9];
   __shared__ int base[9];
   const int t = threadIdx.x, nt = blockDim.x;
   const int chunk = (N + nt - 1) / nt, lo = t * chunk, hi = lo + chunk < N ? lo + chunk : N;
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(1024) sort_perm_kernel(const int* __restrict__
 #pragma unroll
   for (int k = 0; k < 9; k++) cnt[t][k] = c[k];
   __syncthreads();
-  if (t < 9) {   // exclusive scan over threads for bucket t (serial: 1024 adds, negligible)
+  if (t < 9) {   // exclusive scan over threads for bucket t (serial: 256 adds)
     int run = 0;
     for (int j = 0; j < nt; j++) { int v = cnt[j][t]; cnt[j][t] = run; run += v; }
     base[t] = run;
@@ -640,7 +640,7 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
   if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
   if (hipMalloc(&h->sni, sizeof(int) * NI * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
-  h->sort = num_envs >= 256;
+  h->sort = num_envs >= 8192;   // measured: below one full round of waves sorting only adds its own 20 us
   if (const char* ev = getenv("SOLORL_SORT")) h->sort = atoi(ev) != 0 && num_envs >= 2;
   if (h->sort) {
     if (hipMalloc(&h->sf2, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state2"));
@@ -711,7 +711,7 @@ int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* rewa
   }
   if (h->sort) {   // re-sort the state by last contact count (stable), into the spare buffer
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sort_perm_kernel, dim3(1), dim3(1024), 0, st, (const int*)h->si, h->N, h->perm);
+    hipLaunchKernelGGL(sort_perm_kernel, dim3(1), dim3(256), 0, st, (const int*)h->si, h->N, h->perm);
     dim3 g((h->N + 255) / 256, h->L.NF + NI), b(256);
     if (h->f64) hipLaunchKernelGGL(gather_state_kernel<double>, g, b, 0, st, (const double*)h->sf, (const int*)h->si, (const int*)h->perm, h->N, h->L.NF, (double*)h->sf2, h->si2);
     else hipLaunchKernelGGL(gather_state_kernel<float>, g, b, 0, st, (const float*)h->sf, (const int*)h->si, (const int*)h->perm, h->N, h->L.NF, (float*)h->sf2, h->si2);

@@ -1,7 +1,7 @@
 """Time per step vs PGS iterations / frame_skip (not a pytest file)."""
 import os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

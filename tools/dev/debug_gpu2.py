@@ -4,7 +4,7 @@ def log(*a): print("[%.1f]" % (time.time() - t00), *a, flush=True)
 log("start")
 import numpy as np, torch
 log("torch imported", torch.cuda.is_available())
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 from solorl_amd import _native

@@ -2,7 +2,7 @@ import sys, time
 t00 = time.time()
 def log(*a): print("[%.1f]" % (time.time() - t00), *a, flush=True)
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 robot = int(sys.argv[1]); iters = int(sys.argv[2]); settle = int(sys.argv[3]); N = int(sys.argv[4])

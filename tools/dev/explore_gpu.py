@@ -1,7 +1,7 @@
 """Exploratory GPU-vs-oracle comparison (not a pytest file)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 from oracle.oracle_py import Oracle

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 N = 4096
