@@ -12,6 +12,8 @@
  *   solorl_get_observation <- agents/ppo/envs.py:102-105,206-208 -> baseEnv.py:88-89
  *   solorl_dims            <- agents/ppo/envs.py:112-114 (get_spaces) -> baseEnv.py:20-28
  *   solorl_increment_curriculum <- agents/ppo/envs.py:125-127 (pointgoal: solo.py:332-334)
+ *   solorl_compute_returns <- agents/ppo/storage.py:35-55 (OPBuffer.compute_returns: GAE / discounted returns;
+ *                             400 sequential tiny torch ops per update in the reference)
  *   solorl_get_state / solorl_set_state : no reference counterpart (parity-test hooks)
  *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
  *
@@ -134,6 +136,15 @@ int solorl_increment_curriculum(solorl_env* env, double value);
 
 int solorl_get_state(solorl_env* env, int env_index, solorl_env_state* out /* host */);
 int solorl_set_state(solorl_env* env, int env_index, const solorl_env_state* in /* host */);
+
+/* Fused return computation over a rollout of T steps x N envs (device arrays, time-major [t][n]).
+ * use_gae != 0:  value_preds[T][:] = next_value;  delta_t = r_t + gamma V_{t+1} m_{t+1} - V_t;
+ *                A_t = delta_t + gamma lambda m_{t+1} A_{t+1};  returns[t] = A_t + V_t      (storage.py:41-50)
+ * use_gae == 0:  returns[T][:] = next_value;  returns[t] = returns[t+1] gamma m_{t+1} + r_t   (storage.py:51-55) */
+int solorl_compute_returns(const float* rewards /* [T*N] */, float* value_preds /* [(T+1)*N] */,
+                           const float* masks /* [(T+1)*N] */, const float* next_value /* [N] */,
+                           float* returns /* [(T+1)*N] */, int T, int N, int use_gae, float gamma,
+                           float gae_lambda, int device_id, void* stream);
 
 const char* solorl_last_error(void);
 const char* solorl_version(void);

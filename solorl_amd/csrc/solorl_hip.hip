@@ -470,6 +470,37 @@ __global__ void gather_state_kernel(const T* __restrict__ sf, const int* __restr
   else di[(size_t)(f - NF) * N + j] = si[(size_t)(f - NF) * N + src];
 }
 
+// ---- fused GAE / discounted returns (agents/ppo/storage.py:35-55): one thread per env walks the rollout
+// backwards; every access is coalesced across envs.  HBM-bound: 16 B per (t, env) sample.
+__global__ void returns_kernel(const float* __restrict__ rew, float* __restrict__ val, const float* __restrict__ msk,
+                               const float* __restrict__ nextv, float* __restrict__ ret, int T, int N, int use_gae,
+                               float gamma, float lam) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const size_t S = (size_t)N;
+  if (use_gae) {
+    float vnext = nextv[n];
+    val[(size_t)T * S + n] = vnext;
+    float gae = 0.f;
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; t--) {
+      const float m = msk[(size_t)(t + 1) * S + n], v = val[(size_t)t * S + n];
+      const float delta = rew[(size_t)t * S + n] + gamma * vnext * m - v;
+      gae = delta + gamma * lam * m * gae;
+      ret[(size_t)t * S + n] = gae + v;
+      vnext = v;
+    }
+  } else {
+    float r = nextv[n];
+    ret[(size_t)T * S + n] = r;
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; t--) {
+      r = r * gamma * msk[(size_t)(t + 1) * S + n] + rew[(size_t)t * S + n];
+      ret[(size_t)t * S + n] = r;
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================== host side
@@ -590,6 +621,21 @@ int check_cfg(const solorl_config* c) {
 extern "C" {
 
 const char* solorl_last_error(void) { return g_err.c_str(); }
+
+int solorl_compute_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value,
+                           float* returns, int T, int N, int use_gae, float gamma, float gae_lambda, int device_id,
+                           void* stream) {
+  if (!rewards || !value_preds || !masks || !next_value || !returns) return fail(SOLORL_ERR_INVALID, "null array argument");
+  if (T < 1 || N < 1) return fail(SOLORL_ERR_INVALID, "T and N must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SOLORL_ERR_NODEVICE, "no HIP device available (no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(SOLORL_ERR_NODEVICE, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  hipLaunchKernelGGL(returns_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards, value_preds, masks,
+                     next_value, returns, T, N, use_gae, gamma, gae_lambda);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 const char* solorl_version(void) { return "solorl-hip 0.1 (gfx950)"; }
 
 int solorl_default_config(solorl_config* c, int robot, int task) {

@@ -41,6 +41,18 @@ class RolloutStorage:
         """storage.py:35-55.  GAE: delta_t = r_t + g V_{t+1} m_{t+1} - V_t,
         A_t = delta_t + g l m_{t+1} A_{t+1}, R_t = A_t + V_t;  else R_t = r_t + g m_{t+1} R_{t+1}."""
         T = self.num_steps
+        if self.rewards.is_cuda:      # fused HIP kernel (SURVEY.md 8f.1); raises if the engine library is missing
+            import ctypes as C
+            from .. import _native
+            dev = self.rewards.device
+            nv = next_value.detach().to(torch.float32).contiguous()
+            with torch.cuda.device(dev):
+                _native.check(_native.lib().solorl_compute_returns(
+                    C.c_void_p(self.rewards.data_ptr()), C.c_void_p(self.value_preds.data_ptr()),
+                    C.c_void_p(self.masks.data_ptr()), C.c_void_p(nv.data_ptr()), C.c_void_p(self.returns.data_ptr()),
+                    T, self.num_agents, int(bool(use_gae)), float(gamma), float(gae_lambda), dev.index or 0,
+                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            return
         if use_gae:
             self.value_preds[-1].copy_(next_value)
             v, m = self.value_preds, self.masks

@@ -264,3 +264,32 @@ def test_fp64_standing_trajectory(gpu_device):
             worst = max(worst, np.abs(np.array(env.get_state(0).q) - gold["q"][(t + 1) // 50 - 1]).max())
     # actions pass through float32 at the boundary (agents/ppo/envs.py:192), the oracle fixture used float64 actions
     assert worst < 2e-5, worst
+
+
+def test_fused_returns_kernel_matches_reference_golden(gpu_device):
+    """solorl_compute_returns (HIP) vs OPBuffer.compute_returns golden vectors of the reference."""
+    from solorl_amd.ppo import RolloutStorage
+    G = torch.load(os.path.join(GOLDEN, "ppo_golden.pt"), weights_only=False)
+    T, N, O, A = 12, 5, 84, 12
+    s = RolloutStorage(T, N, (O,), A, torch.device("cuda:0"))
+    for k, v in G["buf"].items():
+        getattr(s, k).copy_(v)
+    s.compute_returns(G["next_value"].cuda(), True, 0.99, 0.95)
+    assert torch.allclose(s.returns[:-1].cpu(), G["returns_gae"][:-1], atol=1e-5)
+    assert torch.allclose(s.value_preds.cpu(), G["value_preds_after_gae"])
+    s.compute_returns(G["next_value"].cuda(), False, 0.99, 0.95)
+    assert torch.allclose(s.returns.cpu(), G["returns_disc"], atol=1e-5)
+    # full size vs the torch formulation
+    T, N = 400, 4096
+    big = RolloutStorage(T, N, (4,), 2, torch.device("cuda:0"))
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    big.rewards.copy_(torch.randn(big.rewards.shape, device="cuda:0", generator=g))
+    big.value_preds.copy_(torch.randn(big.value_preds.shape, device="cuda:0", generator=g))
+    big.masks.copy_((torch.rand(big.masks.shape, device="cuda:0", generator=g) > 0.02).float())
+    nv = torch.randn(N, 1, device="cuda:0", generator=g)
+    big.compute_returns(nv, True, 0.99, 0.95)
+    cpu = RolloutStorage(T, N, (4,), 2, torch.device("cpu"))
+    for k in ("rewards", "value_preds", "masks"):
+        getattr(cpu, k).copy_(getattr(big, k).cpu())
+    cpu.compute_returns(nv.cpu(), True, 0.99, 0.95)
+    assert torch.allclose(big.returns[:-1].cpu(), cpu.returns[:-1], atol=2e-4, rtol=1e-4)

@@ -25,3 +25,14 @@ def test_ppo_train_loop_runs_and_learns_something(gpu_device, tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), "solo.pt"), weights_only=False)
     assert set(ck.keys()) == {"update", "state_dict", "ob_rms"} and ck["ob_rms"] is None     # train.py:121-131
     assert "pi_dist.logstd" in ck["state_dict"] and "base.critic.4.weight" in ck["state_dict"]
+    # headless evaluation of that checkpoint (role of testing/test_ppo.py)
+    import sys
+    sys.path.insert(0, root)
+    import eval_ppo
+    dump = os.path.join(str(tmp_path), "traj.npz")
+    r = eval_ppo.main(["--checkpoint-dir", str(tmp_path), "--config-file", os.path.join(root, "configs", "basic12.yaml"),
+                       "--task", "walk", "--num-runs", "8", "--num-agents", "32", "--dump", dump])
+    assert r["episodes"] >= 8 and 1 <= r["mean_length"] <= 400
+    import numpy as np
+    z = np.load(dump)
+    assert z["q"].shape[1] == 12 and z["pos"].shape[1] == 3 and len(z["reward"]) == len(z["q"])
