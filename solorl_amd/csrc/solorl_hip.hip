@@ -234,7 +234,11 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   constexpr int EPB = LDS::LANES;          // envs per workgroup: compile-time (LDS immediates)
   const int t = TEAM ? (threadIdx.x & 15) : 0;
   const int col = TEAM ? (threadIdx.x >> 4) : threadIdx.x;
-  size_t e = (size_t)blockIdx.x * EPB + col;
+  // team mode: a workgroup touches only 16 B of each state field, so eight consecutive workgroups share every
+  // 128-B line; workgroup ids go round-robin over the 8 XCDs (each with its own L2), hence give every XCD one
+  // CONTIGUOUS eighth of the env range instead of every eighth workgroup (grid is a multiple of 8).
+  const unsigned blk = TEAM ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  size_t e = (size_t)blk * EPB + col;
   const bool valid = e < (size_t)N;
   if (!TEAM && !valid) return;
   if (!valid) e = (size_t)N - 1;           // team mode keeps every lane alive for the wave-level exchanges
@@ -544,7 +548,7 @@ template <typename T, int ROBOT>
 int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
   if (h->team) {
     auto kt = step_kernel_team<T, ROBOT>;
-    dim3 grid((N + 3) / 4), block(64);
+    dim3 grid((((N + 3) / 4) + 7) & ~7), block(64);      // multiple of 8: XCD-contiguous env ranges (step_body)
     using TeamLds = RowLds<T, 4>;
     const size_t team_smem = TeamCtx<T, ROBOT, TeamLds>::bytes;
     hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,

@@ -1,6 +1,7 @@
 """Minimal workload for rocprofv3 PMC passes (not a pytest file)."""
 import sys, torch
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 N = 4096
