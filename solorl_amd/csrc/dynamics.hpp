@@ -956,27 +956,33 @@ template <typename T> SD T team_sum16(T x) {
   return x;
 }
 
-// Team-sweep row storage (after the RowLds<T,4> region): per env column
-//   rec  [TR][4][40]   18 (J_c, B_c) pairs, one per accumulator component c (zero for the components of
-//                      other legs, so no masks in the loop) + 2 zero pairs
-//   sca  [TR][4][8]    rhs, 1/diag, mu, lo-multiplier (-1 friction / 0 otherwise), byte offset of the
-//                      parent impulse in `lam` (friction) or of the +inf slot (otherwise), 3 pad
-//   lam  [TR+1][4]     impulses; slot TR holds +1e30 (the "parent" of unilateral rows: hi = mu*1e30)
-// TR = MAX_ROWS + 1: row `nrows` of every env is a null row, so teams with fewer rows than the wave
-// maximum spin on it instead of needing liveness selects.
+// Team-sweep row storage (after the RowLds<T,4> region).  Rows sit at POSITIONS: position = row index, except
+// that the friction block starts at an even position (one null row is inserted when nlim + nc is odd), so a
+// slot (= positions 2k, 2k+1, swept together) is either two unilateral rows or the two friction rows of ONE
+// contact.  Friction rows are stored in units of their contact's mu (lambda~ = lambda/mu, J' = J/mu, B~ = mu B),
+// every row pre-scaled by 1/diag, so the sweep needs no mu and no 1/diag:
+//   rec  [TR][4][38]   18 (J'_c, B~_c) pairs, one per accumulator component c (zero for the components of
+//                      other legs, so no masks in the loop) + 1 zero pair
+//   sca  [TR][4][4]    rhs', coupling c' with the slot partner (odd positions; 0 on even), byte offset of the
+//                      bound cell (parent normal's cell for friction rows, the constant cell otherwise), pad
+//   lam  [TR][4]       impulses (warm start in, result out)
+//   cell [TR+1][4][2]  (hi, lo) bounds a row publishes for its children: (lambda, -lambda); cell TR = (1e30, 0)
 template <typename T, typename LDS> struct TeamRows {
-  static constexpr int TR = MAX_ROWS + 4, REC = 38, SCA = 8, BC = 56;   // + null/padding rows up to the wave maximum (a prefetch
-                                                                       // overrun of one pair lands in the following arrays: harmless)
+  static constexpr int NSLOT = (MAX_ROWS + 2) / 2;          // 14: MAX_ROWS + the alignment row, in pairs
+  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 4, BC = 56;
   static constexpr size_t off_rec = LDS::bytes(4);
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
-  static constexpr size_t off_bc = off_lam + (size_t)(TR + 1) * 4 * sizeof(T);
+  static constexpr size_t off_cell = off_lam + (size_t)TR * 4 * sizeof(T);
+  static constexpr size_t off_bc = off_cell + (size_t)(TR + 1) * 4 * 2 * sizeof(T);
   static constexpr size_t off_ctx = (off_bc + (size_t)4 * BC * sizeof(T) + 15) & ~(size_t)15;   // 4 x SubCtx (size added by the user)
   static constexpr size_t bytes = off_ctx;
-  SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + r*4*REC
-  SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + r*4*SCA
-  SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + r*4
+  SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + pos*4*REC
+  SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + pos*4*SCA
+  SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + pos*4
+  SD static T* cell(int col) { return reinterpret_cast<T*>(solo_smem + off_cell) + col * 2; }      // + pos*8
   SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12
+  SD static int cell_off(int col, int pos) { return (int)off_cell + (pos * 4 + col) * 2 * (int)sizeof(T); }
 };
 
 // leader: base solve, then publish what the row-finishing lanes need
@@ -1007,33 +1013,40 @@ SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size
   hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
 }
 
-// all 16 lanes: lane t finishes rows t, t+16 and writes them as team records
-//   rec: 18 (J_c, B_c) pairs (zero for other legs' components) + 2 zero pairs;  sca: rhs, 1/diag, mu,
-//   lo-multiplier, parent-impulse byte offset;  lam: warm-start impulse
+// number of row positions of this team and the wave maximum (every team sweeps the same slot range)
+template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt, int& nc, int& npos, int& wmax) {
+  const T* hdr = lds.hdr();
+  nlt = (int)hdr[0]; nc = (int)hdr[LDS::LANES];
+  npos = nlt + 3 * nc + ((nlt + nc) & 1);
+  wmax = npos;
+#pragma unroll
+  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
+}
+
+// all 16 lanes: lane t finishes rows t, t+16 and writes them as team records (layout: TeamRows)
 template <typename T, int ROBOT, typename LDS>
 SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
-  constexpr int LN = LDS::LANES;
   const int col = lds.lane;
-  const T* hdr = lds.hdr();
-  const int nlt = (int)hdr[0], nc = (int)hdr[LN], nrows = nlt + 3 * nc, rfric = nlt + nc;
+  int nlt, nc, npos, wmax;
+  team_counts<T, LDS>(lds, nlt, nc, npos, wmax);
+  const int nrows = nlt + 3 * nc, rfric = nlt + nc, pad = rfric & 1;
   T* const rec = TRW::rec(col); T* const sca = TRW::sca(col); T* const lam = TRW::lam(col);
   const T* bc = TRW::bc(col);
-  // null rows from this env's row count up to the (even) wave maximum + 4: the sweep then runs every
-  // team over the same row range with no clamping, and its prefetch may overrun by one pair
-  int wmax = nrows;
-#pragma unroll
-  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
-  const int wpad = ((wmax + 1) & ~1) + 4;
-  if (t == 0) lam[TRW::TR * 4] = T(1e30);
-  for (int r = nrows + t; r < wpad; r += 16) {
+  const int big = TRW::cell_off(col, TRW::TR);
+  if (t == 0) { T* c = TRW::cell(col) + TRW::TR * 8; c[0] = T(1e30); c[1] = T(0); }
+  // null rows: the alignment row and everything from this team's row count up to the (even) wave maximum
+  const int wpad = (wmax + 1) & ~1;
+  auto null_row = [&](int r) {
     T* q = rec + r * (4 * TRW::REC); T* sc = sca + r * (4 * TRW::SCA);
 #pragma unroll
     for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
-    sc[0] = T(0); sc[1] = T(0); sc[2] = T(0); sc[3] = T(0); sc[5] = T(0);
-    *reinterpret_cast<int*>(&sc[4]) = (TRW::TR * 4) * (int)sizeof(T);
+    sc[0] = T(0); sc[1] = T(0);
+    *reinterpret_cast<int*>(&sc[2]) = big;
     lam[r * 4] = T(0);
-  }
+  };
+  for (int r = npos + t; r < wpad; r += 16) null_row(r);
+  if (pad && t == 15) null_row(rfric);
   if (t >= nrows) return;
   Sym6<T> Lam;
 #pragma unroll
@@ -1049,138 +1062,137 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
     const T* ql = bc + 42 + leg * 3;
     SV<T> W; T rhs, dinv;
     finish_row(c, meta, Lam, ub, ql[0], ql[1], ql[2], pp, W, rhs, dinv);
-    T* q = rec + r * (4 * TRW::REC);
-    T* sc = sca + r * (4 * TRW::SCA);
-    q[0] = c[0]; q[1] = W.a.x; q[2] = c[1]; q[3] = W.a.y; q[4] = c[2]; q[5] = W.a.z;
-    q[6] = c[3]; q[7] = W.l.x; q[8] = c[4]; q[9] = W.l.y; q[10] = c[5]; q[11] = W.l.z;
+    const bool fr = r >= rfric;
+    const int pos = r + (fr ? pad : 0);
+    const T sB = fr ? lds.A(r, LDS::A_MU) : T(1);
+    const T sJ = dinv / sB;
+    T* q = rec + pos * (4 * TRW::REC);
+    T* sc = sca + pos * (4 * TRW::SCA);
+    q[0] = c[0] * sJ; q[1] = W.a.x * sB; q[2] = c[1] * sJ; q[3] = W.a.y * sB; q[4] = c[2] * sJ; q[5] = W.a.z * sB;
+    q[6] = c[3] * sJ; q[7] = W.l.x * sB; q[8] = c[4] * sJ; q[9] = W.l.y * sB; q[10] = c[5] * sJ; q[11] = W.l.z * sB;
 #pragma unroll
     for (int k = 12; k < TRW::REC; k++) q[k] = T(0);
     T* ql2 = q + 12 + 6 * leg;
-    ql2[0] = c[6]; ql2[1] = c[15]; ql2[2] = c[7]; ql2[3] = c[16]; ql2[4] = c[8]; ql2[5] = c[17];
-    const bool fr = r >= rfric;
-    sc[0] = rhs; sc[1] = dinv;
-    sc[2] = fr ? lds.A(r, LDS::A_MU) : T(1); sc[3] = fr ? T(-1) : T(0);
-    const int par = fr ? nlt + ((r - rfric) >> 1) : TRW::TR;
-    *reinterpret_cast<int*>(&sc[4]) = (par * 4) * (int)sizeof(T);
-    lam[r * 4] = c[13];       // warm-start impulse (0 for friction / limit rows)
+    ql2[0] = c[6] * sJ; ql2[1] = c[15] * sB; ql2[2] = c[7] * sJ; ql2[3] = c[16] * sB; ql2[4] = c[8] * sJ; ql2[5] = c[17] * sB;
+    sc[0] = rhs / sB; sc[1] = T(0);     // finish_row's rhs already carries 1/diag
+    *reinterpret_cast<int*>(&sc[2]) = fr ? TRW::cell_off(col, nlt + ((r - rfric) >> 1)) : big;
+    lam[pos * 4] = c[13];     // warm-start impulse (0 for friction / limit rows)
   }
 }
 
-// coupling of the row pairs (2m, 2m+1) swept together: c_m = J_{2m+1} . B_{2m}   (lane m computes pair m)
+// coupling of the two rows of a slot: c'_k = J'_{2k+1} . B~_{2k}   (lane k computes slot k)
 template <typename T, typename LDS>
 SNI void phase_pair_coupling(const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
-  constexpr int LN = LDS::LANES;
   const int col = lds.lane;
-  const T* hdr = lds.hdr();
-  const int nrows = (int)hdr[0] + 3 * (int)hdr[LN];
-  if (2 * t >= nrows) return;
+  int nlt, nc, npos, wmax;
+  team_counts<T, LDS>(lds, nlt, nc, npos, wmax);
+  if (2 * t >= npos) return;
   const T* r0 = TRW::rec(col) + (2 * t) * (4 * TRW::REC);
   const T* r1 = r0 + 4 * TRW::REC;
   T c = T(0);
 #pragma unroll
   for (int k = 0; k < 18; k++) c += r1[2 * k] * r0[2 * k + 1];
-  TRW::sca(col)[(2 * t + 1) * (4 * TRW::SCA) + 5] = c;
+  TRW::sca(col)[(2 * t + 1) * (4 * TRW::SCA) + 1] = c;
 }
 
-// Pair sweep: rows 2m and 2m+1 are updated in one step.  Each 8-lane half of the DPP row holds a
-// full copy of the 18 accumulator components (3 per lane); half 0 reduces row 2m's dot product and
-// half 1 row 2m+1's AT THE SAME TIME against the pre-update accumulators; the Gauss-Seidel dependency
-// is restored analytically:  J_{2m+1}.(acc + B_{2m} d0) = J_{2m+1}.acc + c_m d0.  This is a
-// re-association of the same sums (parity bounds unchanged).  Every team's rows are padded with null
-// rows to the wave maximum, so the loop has no clamps and all LDS accesses are running 32-bit byte
-// offsets with immediate displacements.
+// exchange between the two 8-lane halves of a 16-lane team (values are uniform within a half)
+template <typename T> SD T half_swap(T x) {
+  if constexpr (sizeof(T) == 4) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+  else return __shfl_xor(x, 8, 16);
+}
+template <typename T> SD T clamp3(T x, T lo, T hi) {
+  if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, lo, hi);
+  else return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// Register-resident slot sweep.  Each 8-lane half of the team holds a full copy of the 18 accumulator
+// components (3 per lane); in slot k half 0 owns row 2k and half 1 row 2k+1, and every lane keeps ITS row's
+// J', B~, rhs', impulse and bound-cell offset plus the partner row's B~ in VGPRs for the whole solve (the
+// slot loop is fully unrolled, so all of it is statically indexed): 50 sweeps touch LDS only for the bound
+// cells.  Both halves reduce their own row's J'.acc at the same time against the pre-update accumulators;
+// the Gauss-Seidel dependency of row 2k+1 on row 2k is restored analytically,
+//   J'_{2k+1}.(acc + B~_{2k} d0) = J'_{2k+1}.acc + c'_k d0,
+// a re-association of the same sums.  Teams are padded with null rows to the wave maximum.
 template <typename T, int ROBOT, typename LDS>
 SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
-  constexpr int LN = LDS::LANES;
+  constexpr int LN = LDS::LANES, NS = TRW::NSLOT;
   const int col = lds.lane;
-  T* const hdr = lds.hdr();
-  const int nlt = (int)hdr[0], nc = (int)hdr[LN];
-  const int nrows = nlt + 3 * nc;
-  int wmax = nrows;
-#pragma unroll
-  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
-  const int npairs2 = (wmax + 3) >> 2;          // loop trips: two pairs per trip
+  int nlt, nc, npos, wmax;
+  team_counts<T, LDS>(lds, nlt, nc, npos, wmax);
+  const int nslots = __builtin_amdgcn_readfirstlane((wmax + 1) >> 1);     // wave-uniform: scalar branches
   const int h = t & 7, half = t >> 3;
   const int cc = h < 2 ? 16 + h : 18;           // third accumulator component (or the zero pair)
   constexpr int SZ = (int)sizeof(T);
-  constexpr int S_REC = 4 * TRW::REC * SZ, S_SCA = 4 * TRW::SCA * SZ, S_LAM = 4 * SZ;
+  constexpr int S_REC = 4 * TRW::REC * SZ, S_SCA = 4 * TRW::SCA * SZ, S_LAM = 4 * SZ, S_CELL = 8 * SZ;
   constexpr int dB = 2 * 8 * SZ;
   const int dC = 2 * (cc - h) * SZ;
   using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
-  using P4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
   auto ldT = [&](int off) -> T { return *reinterpret_cast<const T*>(solo_smem + off); };
   auto ldI = [&](int off) -> int { return *reinterpret_cast<const int*>(solo_smem + off); };
   auto ld2 = [&](int off) -> P2 { return *reinterpret_cast<const P2*>(solo_smem + off); };
-  auto ld4 = [&](int off) -> P4 { return *reinterpret_cast<const P4*>(solo_smem + off); };
-  const int rec0 = (int)TRW::off_rec + (col * TRW::REC + 2 * h) * SZ;     // pair h of row 0
-  const int sca0 = (int)TRW::off_sca + col * TRW::SCA * SZ;
-  const int lam0 = (int)TRW::off_lam + col * SZ;
-  // warm start: acc_c = sum over the normal rows of B_c * lam0   (dV = M^-1 J^T lam0)
+  const int rec_own = (int)TRW::off_rec + (col * TRW::REC + 2 * h) * SZ + half * S_REC;
+  const int rec_oth = rec_own + (1 - 2 * half) * S_REC;
+  const int sca_own = (int)TRW::off_sca + col * TRW::SCA * SZ + half * S_SCA;
+  const int lam_own = (int)TRW::off_lam + col * SZ + half * S_LAM;
+  const int cell_own = TRW::cell_off(col, half);
+  T J0[NS], J1[NS], J2[NS], B0[NS], B1[NS], B2[NS], X0[NS], X1[NS], X2[NS], rh[NS], cp[NS], lm[NS];
+  int pc[NS];
   T a0 = T(0), a1 = T(0), a2 = T(0);
-  for (int r = nlt; r < nlt + nc; r++) {
-    const T l0 = ldT(lam0 + r * S_LAM);
-    a0 += ld2(rec0 + r * S_REC).y * l0; a1 += ld2(rec0 + r * S_REC + dB).y * l0; a2 += ld2(rec0 + r * S_REC + dC).y * l0;
-  }
-  struct Pair { P2 o0, o1, o2, x0, x1, x2; P4 sA, sB; int p0, p1; T cpl, lam0, lam1; };
-  // own = the row this half reduces (2m + half), other = its partner
-  auto fetch = [&](int own, int oth, int sc, int la, Pair& R) {
-    R.o0 = ld2(own); R.o1 = ld2(own + dB); R.o2 = ld2(own + dC);
-    R.x0 = ld2(oth); R.x1 = ld2(oth + dB); R.x2 = ld2(oth + dC);
-    R.sA = ld4(sc); R.p0 = ldI(sc + 4 * SZ);
-    R.sB = ld4(sc + S_SCA); R.p1 = ldI(sc + S_SCA + 4 * SZ); R.cpl = ldT(sc + S_SCA + 5 * SZ);
-    R.lam0 = ldT(la); R.lam1 = ldT(la + S_LAM);
-  };
-  auto step = [&](int la, Pair& R) {
-    const T lp0 = ldT(lam0 + R.p0);              // parents' impulses: issued after the previous pair's stores -> fresh
-    const T lp1r = ldT(lam0 + R.p1);
-    T d = R.o0.x * a0 + R.o1.x * a1 + R.o2.x * a2;   // 8-lane butterfly: both halves reduce their own row at once
-    T dx;
-    if constexpr (sizeof(T) == 4) {
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
-      dx = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));   // row_mirror: other half
-    } else {
-      d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16);
-      dx = __shfl_xor(d, 8, 16);
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    J0[k] = J1[k] = J2[k] = B0[k] = B1[k] = B2[k] = X0[k] = X1[k] = X2[k] = rh[k] = cp[k] = lm[k] = T(0); pc[k] = 0;
+    if (k < nslots) {
+      const P2 u = ld2(rec_own + 2 * k * S_REC), v = ld2(rec_own + 2 * k * S_REC + dB), w = ld2(rec_own + 2 * k * S_REC + dC);
+      J0[k] = u.x; B0[k] = u.y; J1[k] = v.x; B1[k] = v.y; J2[k] = w.x; B2[k] = w.y;
+      X0[k] = ldT(rec_oth + 2 * k * S_REC + SZ); X1[k] = ldT(rec_oth + 2 * k * S_REC + dB + SZ); X2[k] = ldT(rec_oth + 2 * k * S_REC + dC + SZ);
+      const P2 s = ld2(sca_own + 2 * k * S_SCA);
+      rh[k] = s.x; cp[k] = s.y; pc[k] = ldI(sca_own + 2 * k * S_SCA + 2 * SZ);
+      lm[k] = ldT(lam_own + 2 * k * S_LAM);
+      // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
+      const T lx = half_swap(lm[k]);
+      a0 += B0[k] * lm[k] + X0[k] * lx; a1 += B1[k] * lm[k] + X1[k] * lx; a2 += B2[k] * lm[k] + X2[k] * lx;
     }
-    const T d0 = half ? dx : d, d1 = half ? d : dx;
-    // row 2m:  sA = rhs, 1/diag, mu, lo-multiplier
-    const T hi0 = R.sA.z * lp0, lo0 = R.sA.w * hi0;
-    T s0 = R.lam0 + (R.sA.x - d0 * R.sA.y);
-    if constexpr (sizeof(T) == 4) s0 = __builtin_amdgcn_fmed3f(s0, lo0, hi0); else s0 = s0 < lo0 ? lo0 : (s0 > hi0 ? hi0 : s0);
-    const T del0 = s0 - R.lam0;
-    // row 2m+1 sees row 2m's update through the coupling; its parent may be row 2m
-    const T lp1 = (lam0 + R.p1) == la ? s0 : lp1r;
-    const T hi1 = R.sB.z * lp1, lo1 = R.sB.w * hi1;
-    T s1 = R.lam1 + (R.sB.x - (d1 + R.cpl * del0) * R.sB.y);
-    if constexpr (sizeof(T) == 4) s1 = __builtin_amdgcn_fmed3f(s1, lo1, hi1); else s1 = s1 < lo1 ? lo1 : (s1 > hi1 ? hi1 : s1);
-    const T del1 = s1 - R.lam1;
-    const T dself = half ? del1 : del0, doth = half ? del0 : del1;
-    a0 += R.o0.y * dself + R.x0.y * doth;
-    a1 += R.o1.y * dself + R.x1.y * doth;
-    a2 += R.o2.y * dself + R.x2.y * doth;
-    *reinterpret_cast<T*>(solo_smem + la) = s0;
-    *reinterpret_cast<T*>(solo_smem + la + S_LAM) = s1;
-  };
-  const int own0 = rec0 + half * S_REC, oth0 = rec0 + (1 - half) * S_REC;
+  }
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
-    Pair A, B;
-    int own = own0, oth = oth0, sc = sca0, la = lam0;
-    fetch(own, oth, sc, la, A);
-#pragma unroll 1
-    for (int k = 0; k < npairs2; k++) {
-      fetch(own + 2 * S_REC, oth + 2 * S_REC, sc + 2 * S_SCA, la + 2 * S_LAM, B);
-      step(la, A);
-      fetch(own + 4 * S_REC, oth + 4 * S_REC, sc + 4 * S_SCA, la + 4 * S_LAM, A);
-      step(la + 2 * S_LAM, B);
-      own += 4 * S_REC; oth += 4 * S_REC; sc += 4 * S_SCA; la += 4 * S_LAM;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      if (k < nslots) {
+      const P2 bd = ld2(pc[k]);                         // (hi, lo): written by the parent earlier in this sweep
+      T d = J0[k] * a0 + J1[k] * a1 + J2[k] * a2;       // 8-lane butterfly: both halves reduce their own row at once
+      if constexpr (sizeof(T) == 4) {
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
+      } else {
+        d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16);
+      }
+      T sp = (lm[k] + rh[k]) - d;
+      // row 2k (half 0) is final after the first clamp; row 2k+1 (half 1) then sees its delta through c'
+      // (cp = 0 in half 0, whose second clamp therefore repeats the first)
+      const T dfirst = clamp3(sp, bd.y, bd.x) - lm[k];
+      sp -= cp[k] * half_swap(dfirst);
+      const T s = clamp3(sp, bd.y, bd.x);
+      const T del = s - lm[k];
+      lm[k] = s;
+      const T delx = half_swap(del);
+      a0 += B0[k] * del + X0[k] * delx;
+      a1 += B1[k] * del + X1[k] * delx;
+      a2 += B2[k] * del + X2[k] * delx;
+      P2 nb; nb.x = s; nb.y = -s;
+      *reinterpret_cast<P2*>(solo_smem + cell_own + k * 2 * S_CELL) = nb;
+      }
     }
   }
-  // accumulators back to LDS for the leader (half 0 holds the same values as half 1)
+  // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
+  if (h == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+      if (k < nslots) *reinterpret_cast<T*>(solo_smem + lam_own + 2 * k * S_LAM) = lm[k];
+  }
+  T* const hdr = lds.hdr();
   if (half == 0) {
     if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0;
     lds.y()[(h + 2) * LN] = a1;
