@@ -956,33 +956,36 @@ template <typename T> SD T team_sum16(T x) {
   return x;
 }
 
-// Team-sweep row storage (after the RowLds<T,4> region).  Rows sit at POSITIONS: position = row index, except
-// that the friction block starts at an even position (one null row is inserted when nlim + nc is odd), so a
-// slot (= positions 2k, 2k+1, swept together) is either two unilateral rows or the two friction rows of ONE
-// contact.  Friction rows are stored in units of their contact's mu (lambda~ = lambda/mu, J' = J/mu, B~ = mu B),
-// every row pre-scaled by 1/diag, so the sweep needs no mu and no 1/diag:
+// Team-sweep row storage (after the RowLds<T,4> region).  Rows sit at STATIC positions, two per slot:
+//   slot 0        positions 0,1           the (<= 2) joint-limit rows
+//   slots 1..4    positions 2+k           normal row of contact k (k = rank of its primitive among the contacts)
+//   slots 5..12   positions 10+2k, 11+2k  the two friction rows of contact k
+// which keeps the solver order [limits | normals | friction pairs] (unused positions inside a swept slot are
+// null rows) and makes the parent of friction slot 5+k a compile-time register: the impulse of slot 1+k/2,
+// half k&1.  Friction rows are stored in units of their contact's mu (lambda~ = lambda/mu, J' = J/mu,
+// B~ = mu B) and every row is pre-scaled by 1/diag, so the sweep needs neither mu nor 1/diag:
 //   rec  [TR][4][38]   18 (J'_c, B~_c) pairs, one per accumulator component c (zero for the components of
 //                      other legs, so no masks in the loop) + 1 zero pair
-//   sca  [TR][4][4]    rhs', coupling c' with the slot partner (odd positions; 0 on even), byte offset of the
-//                      bound cell (parent normal's cell for friction rows, the constant cell otherwise), pad
+//   sca  [TR][4][2]    rhs', coupling c' with the slot partner (odd positions; 0 on even)
 //   lam  [TR][4]       impulses (warm start in, result out)
-//   cell [TR+1][4][2]  (hi, lo) bounds a row publishes for its children: (lambda, -lambda); cell TR = (1e30, 0)
 template <typename T, typename LDS> struct TeamRows {
-  static constexpr int NSLOT = (MAX_ROWS + 2) / 2;          // 14: MAX_ROWS + the alignment row, in pairs
-  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 4, BC = 56;
+  static_assert(MAX_LIMITS == 2 && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
+  static constexpr int NPOS0 = 2, FPOS0 = NPOS0 + MAX_CONTACTS;              // first normal / friction position
+  static constexpr int NSLOT = 1 + MAX_CONTACTS / 2 + MAX_CONTACTS;          // 13
+  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 2, BC = 56;
   static constexpr size_t off_rec = LDS::bytes(4);
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
-  static constexpr size_t off_cell = off_lam + (size_t)TR * 4 * sizeof(T);
-  static constexpr size_t off_bc = off_cell + (size_t)(TR + 1) * 4 * 2 * sizeof(T);
+  static constexpr size_t off_bc = off_lam + (size_t)TR * 4 * sizeof(T);
   static constexpr size_t off_ctx = (off_bc + (size_t)4 * BC * sizeof(T) + 15) & ~(size_t)15;   // 4 x SubCtx (size added by the user)
   static constexpr size_t bytes = off_ctx;
   SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + pos*4*REC
   SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + pos*4*SCA
   SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + pos*4
-  SD static T* cell(int col) { return reinterpret_cast<T*>(solo_smem + off_cell) + col * 2; }      // + pos*8
   SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12
-  SD static int cell_off(int col, int pos) { return (int)off_cell + (pos * 4 + col) * 2 * (int)sizeof(T); }
+  SD static int pos_of(int r, int nlt, int nc) {   // solver row index -> position
+    return r < nlt ? r : (r < nlt + nc ? NPOS0 + (r - nlt) : FPOS0 + (r - nlt - nc));
+  }
 };
 
 // leader: base solve, then publish what the row-finishing lanes need
@@ -1013,14 +1016,15 @@ SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size
   hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
 }
 
-// number of row positions of this team and the wave maximum (every team sweeps the same slot range)
-template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt, int& nc, int& npos, int& wmax) {
+// this team's row counts and the wave-uniform sweep extent (every team of the wave sweeps the same slots)
+template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt, int& nc, int& ncmax, int& anylim) {
   const T* hdr = lds.hdr();
   nlt = (int)hdr[0]; nc = (int)hdr[LDS::LANES];
-  npos = nlt + 3 * nc + ((nlt + nc) & 1);
-  wmax = npos;
+  int m = nc | (nlt << 8);
 #pragma unroll
-  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(wmax, o); wmax = v > wmax ? v : wmax; }
+  for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(m, o); m = ((v & 255) > (m & 255) ? (v & 255) : (m & 255)) | ((v | m) & ~255); }
+  m = __builtin_amdgcn_readfirstlane(m);          // identical in all lanes: scalar branches in the sweep
+  ncmax = m & 255; anylim = m >> 8;
 }
 
 // all 16 lanes: lane t finishes rows t, t+16 and writes them as team records (layout: TeamRows)
@@ -1028,25 +1032,24 @@ template <typename T, int ROBOT, typename LDS>
 SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
   const int col = lds.lane;
-  int nlt, nc, npos, wmax;
-  team_counts<T, LDS>(lds, nlt, nc, npos, wmax);
-  const int nrows = nlt + 3 * nc, rfric = nlt + nc, pad = rfric & 1;
+  int nlt, nc, ncmax, anylim;
+  team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
+  const int nrows = nlt + 3 * nc, rfric = nlt + nc;
   T* const rec = TRW::rec(col); T* const sca = TRW::sca(col); T* const lam = TRW::lam(col);
   const T* bc = TRW::bc(col);
-  const int big = TRW::cell_off(col, TRW::TR);
-  if (t == 0) { T* c = TRW::cell(col) + TRW::TR * 8; c[0] = T(1e30); c[1] = T(0); }
-  // null rows: the alignment row and everything from this team's row count up to the (even) wave maximum
-  const int wpad = (wmax + 1) & ~1;
-  auto null_row = [&](int r) {
-    T* q = rec + r * (4 * TRW::REC); T* sc = sca + r * (4 * TRW::SCA);
+  // null rows: unused positions of the slots the wave will sweep
+  const int nce = (ncmax + 1) & ~1;
+  for (int pos = t; pos < TRW::TR; pos += 16) {
+    const int kn = pos - TRW::NPOS0, kf = pos - TRW::FPOS0;
+    const bool z = pos < TRW::NPOS0 ? (anylim && pos >= nlt) : (pos < TRW::FPOS0 ? (kn >= nc && kn < nce) : (kf >= 2 * nc && kf < 2 * ncmax));
+    if (z) {
+      T* q = rec + pos * (4 * TRW::REC); T* sc = sca + pos * (4 * TRW::SCA);
 #pragma unroll
-    for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
-    sc[0] = T(0); sc[1] = T(0);
-    *reinterpret_cast<int*>(&sc[2]) = big;
-    lam[r * 4] = T(0);
-  };
-  for (int r = npos + t; r < wpad; r += 16) null_row(r);
-  if (pad && t == 15) null_row(rfric);
+      for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
+      sc[0] = T(0); sc[1] = T(0);
+      lam[pos * 4] = T(0);
+    }
+  }
   if (t >= nrows) return;
   Sym6<T> Lam;
 #pragma unroll
@@ -1063,7 +1066,7 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
     SV<T> W; T rhs, dinv;
     finish_row(c, meta, Lam, ub, ql[0], ql[1], ql[2], pp, W, rhs, dinv);
     const bool fr = r >= rfric;
-    const int pos = r + (fr ? pad : 0);
+    const int pos = TRW::pos_of(r, nlt, nc);
     const T sB = fr ? lds.A(r, LDS::A_MU) : T(1);
     const T sJ = dinv / sB;
     T* q = rec + pos * (4 * TRW::REC);
@@ -1075,19 +1078,17 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
     T* ql2 = q + 12 + 6 * leg;
     ql2[0] = c[6] * sJ; ql2[1] = c[15] * sB; ql2[2] = c[7] * sJ; ql2[3] = c[16] * sB; ql2[4] = c[8] * sJ; ql2[5] = c[17] * sB;
     sc[0] = rhs / sB; sc[1] = T(0);     // finish_row's rhs already carries 1/diag
-    *reinterpret_cast<int*>(&sc[2]) = fr ? TRW::cell_off(col, nlt + ((r - rfric) >> 1)) : big;
-    lam[pos * 4] = c[13];     // warm-start impulse (0 for friction / limit rows)
+    lam[pos * 4] = c[13];               // warm-start impulse (0 for friction / limit rows)
   }
 }
 
-// coupling of the two rows of a slot: c'_k = J'_{2k+1} . B~_{2k}   (lane k computes slot k)
+// coupling of the two rows of a slot: c'_k = J'_{2k+1} . B~_{2k}   (lane k computes slot k; slots the sweep
+// skips hold stale rows -- their coupling is never read)
 template <typename T, typename LDS>
 SNI void phase_pair_coupling(const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
   const int col = lds.lane;
-  int nlt, nc, npos, wmax;
-  team_counts<T, LDS>(lds, nlt, nc, npos, wmax);
-  if (2 * t >= npos) return;
+  if (t >= TRW::NSLOT) return;
   const T* r0 = TRW::rec(col) + (2 * t) * (4 * TRW::REC);
   const T* r1 = r0 + 4 * TRW::REC;
   T c = T(0);
@@ -1101,96 +1102,105 @@ template <typename T> SD T half_swap(T x) {
   if constexpr (sizeof(T) == 4) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
   else return __shfl_xor(x, 8, 16);
 }
-template <typename T> SD T clamp3(T x, T lo, T hi) {
-  if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, lo, hi);
-  else return x < lo ? lo : (x > hi ? hi : x);
-}
 
 // Register-resident slot sweep.  Each 8-lane half of the team holds a full copy of the 18 accumulator
-// components (3 per lane); in slot k half 0 owns row 2k and half 1 row 2k+1, and every lane keeps ITS row's
-// J', B~, rhs', impulse and bound-cell offset plus the partner row's B~ in VGPRs for the whole solve (the
-// slot loop is fully unrolled, so all of it is statically indexed): 50 sweeps touch LDS only for the bound
-// cells.  Both halves reduce their own row's J'.acc at the same time against the pre-update accumulators;
-// the Gauss-Seidel dependency of row 2k+1 on row 2k is restored analytically,
+// components (3 per lane); in slot k half 0 owns position 2k and half 1 position 2k+1, and every lane keeps
+// ITS row's J', B~, rhs' and impulse plus the partner row's B~ in VGPRs for the whole solve (the slot loops
+// are fully unrolled, so everything is statically indexed): the 50 sweeps never touch memory.  Both halves
+// reduce their own row's J'.acc at the same time against the pre-update accumulators; the Gauss-Seidel
+// dependency of position 2k+1 on 2k is restored analytically,
 //   J'_{2k+1}.(acc + B~_{2k} d0) = J'_{2k+1}.acc + c'_k d0,
-// a re-association of the same sums.  Teams are padded with null rows to the wave maximum.
+// a re-association of the same sums.  Slots are skipped on wave-uniform conditions (any limit row in the
+// wave; the wave's largest contact count), so teams with fewer rows sweep null rows.
 template <typename T, int ROBOT, typename LDS>
 SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
-  constexpr int LN = LDS::LANES, NS = TRW::NSLOT;
+  constexpr int LN = LDS::LANES, NS = TRW::NSLOT, NN = MAX_CONTACTS / 2, S_N0 = 1, S_F0 = 1 + NN;
   const int col = lds.lane;
-  int nlt, nc, npos, wmax;
-  team_counts<T, LDS>(lds, nlt, nc, npos, wmax);
-  const int nslots = __builtin_amdgcn_readfirstlane((wmax + 1) >> 1);     // wave-uniform: scalar branches
+  int nlt, nc, ncmax, anylim;
+  team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
   const int h = t & 7, half = t >> 3;
   const int cc = h < 2 ? 16 + h : 18;           // third accumulator component (or the zero pair)
   constexpr int SZ = (int)sizeof(T);
-  constexpr int S_REC = 4 * TRW::REC * SZ, S_SCA = 4 * TRW::SCA * SZ, S_LAM = 4 * SZ, S_CELL = 8 * SZ;
+  constexpr int S_REC = 4 * TRW::REC * SZ, S_SCA = 4 * TRW::SCA * SZ, S_LAM = 4 * SZ;
   constexpr int dB = 2 * 8 * SZ;
   const int dC = 2 * (cc - h) * SZ;
   using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
   auto ldT = [&](int off) -> T { return *reinterpret_cast<const T*>(solo_smem + off); };
-  auto ldI = [&](int off) -> int { return *reinterpret_cast<const int*>(solo_smem + off); };
   auto ld2 = [&](int off) -> P2 { return *reinterpret_cast<const P2*>(solo_smem + off); };
   const int rec_own = (int)TRW::off_rec + (col * TRW::REC + 2 * h) * SZ + half * S_REC;
   const int rec_oth = rec_own + (1 - 2 * half) * S_REC;
   const int sca_own = (int)TRW::off_sca + col * TRW::SCA * SZ + half * S_SCA;
   const int lam_own = (int)TRW::off_lam + col * SZ + half * S_LAM;
-  const int cell_own = TRW::cell_off(col, half);
   T J0[NS], J1[NS], J2[NS], B0[NS], B1[NS], B2[NS], X0[NS], X1[NS], X2[NS], rh[NS], cp[NS], lm[NS];
-  int pc[NS];
+  T lmx[NN];                                    // the partner half's impulse of the normal slots (friction bounds)
   T a0 = T(0), a1 = T(0), a2 = T(0);
+  auto live = [&](int k) -> bool { return k < S_N0 ? anylim != 0 : (k < S_F0 ? 2 * (k - S_N0) < ncmax : (k - S_F0) < ncmax); };
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    J0[k] = J1[k] = J2[k] = B0[k] = B1[k] = B2[k] = X0[k] = X1[k] = X2[k] = rh[k] = cp[k] = lm[k] = T(0); pc[k] = 0;
-    if (k < nslots) {
+    J0[k] = J1[k] = J2[k] = B0[k] = B1[k] = B2[k] = X0[k] = X1[k] = X2[k] = rh[k] = cp[k] = lm[k] = T(0);
+    if (k >= S_N0 && k < S_F0) lmx[k - S_N0] = T(0);
+    if (live(k)) {
       const P2 u = ld2(rec_own + 2 * k * S_REC), v = ld2(rec_own + 2 * k * S_REC + dB), w = ld2(rec_own + 2 * k * S_REC + dC);
       J0[k] = u.x; B0[k] = u.y; J1[k] = v.x; B1[k] = v.y; J2[k] = w.x; B2[k] = w.y;
       X0[k] = ldT(rec_oth + 2 * k * S_REC + SZ); X1[k] = ldT(rec_oth + 2 * k * S_REC + dB + SZ); X2[k] = ldT(rec_oth + 2 * k * S_REC + dC + SZ);
       const P2 s = ld2(sca_own + 2 * k * S_SCA);
-      rh[k] = s.x; cp[k] = s.y; pc[k] = ldI(sca_own + 2 * k * S_SCA + 2 * SZ);
+      rh[k] = s.x; cp[k] = s.y;
       lm[k] = ldT(lam_own + 2 * k * S_LAM);
       // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
       const T lx = half_swap(lm[k]);
+      if (k >= S_N0 && k < S_F0) lmx[k - S_N0] = lx;
       a0 += B0[k] * lm[k] + X0[k] * lx; a1 += B1[k] * lm[k] + X1[k] * lx; a2 += B2[k] * lm[k] + X2[k] * lx;
     }
   }
+  // one slot: bounds [lo, hi] = [0, inf) for unilateral rows, [-hi, hi] for the friction rows of a contact
+  auto slot = [&](int k, bool fric, T hi, T& delx_out) {
+    T d = J0[k] * a0 + J1[k] * a1 + J2[k] * a2;       // 8-lane butterfly: both halves reduce their own row at once
+    if constexpr (sizeof(T) == 4) {
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
+    } else {
+      d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16);
+    }
+    auto clampb = [&](T x) -> T {
+      if (!fric) return x > T(0) ? x : T(0);
+      if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, -hi, hi);
+      else return x < -hi ? -hi : (x > hi ? hi : x);
+    };
+    T sp = (lm[k] + rh[k]) - d;
+    // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
+    // (cp = 0 in half 0, whose second clamp therefore repeats the first)
+    const T dfirst = clampb(sp) - lm[k];
+    sp -= cp[k] * half_swap(dfirst);
+    const T s = clampb(sp);
+    const T del = s - lm[k];
+    lm[k] = s;
+    const T delx = half_swap(del);
+    a0 += B0[k] * del + X0[k] * delx;
+    a1 += B1[k] * del + X1[k] * delx;
+    a2 += B2[k] * del + X2[k] * delx;
+    delx_out = delx;
+  };
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
+    T dx;
+    if (anylim) slot(0, false, T(0), dx);
 #pragma unroll
-    for (int k = 0; k < NS; k++) {
-      if (k < nslots) {
-      const P2 bd = ld2(pc[k]);                         // (hi, lo): written by the parent earlier in this sweep
-      T d = J0[k] * a0 + J1[k] * a1 + J2[k] * a2;       // 8-lane butterfly: both halves reduce their own row at once
-      if constexpr (sizeof(T) == 4) {
-        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
-        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
-        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
-      } else {
-        d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16);
+    for (int m = 0; m < NN; m++)
+      if (2 * m < ncmax) { slot(S_N0 + m, false, T(0), dx); lmx[m] += dx; }
+#pragma unroll
+    for (int k = 0; k < MAX_CONTACTS; k++)
+      if (k < ncmax) {
+        const T hi = (half == (k & 1)) ? lm[S_N0 + (k >> 1)] : lmx[k >> 1];     // impulse of contact k's normal row
+        slot(S_F0 + k, true, hi, dx);
       }
-      T sp = (lm[k] + rh[k]) - d;
-      // row 2k (half 0) is final after the first clamp; row 2k+1 (half 1) then sees its delta through c'
-      // (cp = 0 in half 0, whose second clamp therefore repeats the first)
-      const T dfirst = clamp3(sp, bd.y, bd.x) - lm[k];
-      sp -= cp[k] * half_swap(dfirst);
-      const T s = clamp3(sp, bd.y, bd.x);
-      const T del = s - lm[k];
-      lm[k] = s;
-      const T delx = half_swap(del);
-      a0 += B0[k] * del + X0[k] * delx;
-      a1 += B1[k] * del + X1[k] * delx;
-      a2 += B2[k] * del + X2[k] * delx;
-      P2 nb; nb.x = s; nb.y = -s;
-      *reinterpret_cast<P2*>(solo_smem + cell_own + k * 2 * S_CELL) = nb;
-      }
-    }
   }
   // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
   if (h == 0) {
 #pragma unroll
     for (int k = 0; k < NS; k++)
-      if (k < nslots) *reinterpret_cast<T*>(solo_smem + lam_own + 2 * k * S_LAM) = lm[k];
+      if (live(k)) *reinterpret_cast<T*>(solo_smem + lam_own + 2 * k * S_LAM) = lm[k];
   }
   T* const hdr = lds.hdr();
   if (half == 0) {
@@ -1232,11 +1242,11 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
       for (int k = 0; k < 3; k++) C.y[l][k] = lds.y()[(l * 3 + k) * LN];
     const T* lam = TRW::lam(lds.lane);
     // impulses back into the lane-layout aux (phase_integrate reads the base primitives' there)
-    for (int r = C.nlim_total; r < C.nlim_total + C.nc; r++) lds.A(r, LDS::A_LAM) = lam[r * 4];
+    for (int k = 0; k < C.nc; k++) lds.A(C.nlim_total + k, LDS::A_LAM) = lam[(TRW::NPOS0 + k) * 4];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int p = 12 + i;
-      C.lam_n[i] = ((C.mask >> p) & 1) ? lam[(C.nlim_total + __popc(C.mask & ((1 << p) - 1))) * 4] : T(0);
+      C.lam_n[i] = ((C.mask >> p) & 1) ? lam[(TRW::NPOS0 + __popc(C.mask & ((1 << p) - 1))) * 4] : T(0);
     }
     phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
     mask = C.mask;
