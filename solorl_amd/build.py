@@ -23,6 +23,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
            "-I" + os.path.join(ROOT, "include"), "-o", LIB + ".tmp", SRC[0]]
+    cmd[1:1] = ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -325,8 +325,9 @@ SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
     leg_prim_points<T, ROBOT, L>(R0, sn, cs, kneeP, footP);
     C.kneeP[L] = kneeP; C.footP[L] = footP;
     dist[12 + 2 * L] = st.pos.z + kneeP.z; dist[13 + 2 * L] = st.pos.z + footP.z;
-    if (dist[12 + 2 * L] < T(RB::MD.prims[12 + 2 * L].margin)) mask |= 1 << (12 + 2 * L);
-    if (dist[13 + 2 * L] < T(RB::MD.prims[13 + 2 * L].margin)) mask |= 1 << (13 + 2 * L);
+    constexpr double mk_ = RB::MD.prims[12 + 2 * L].margin, mf_ = RB::MD.prims[13 + 2 * L].margin;   // (constexpr: no run-time model loads)
+    if (dist[12 + 2 * L] < T(mk_)) mask |= 1 << (12 + 2 * L);
+    if (dist[13 + 2 * L] < T(mf_)) mask |= 1 << (13 + 2 * L);
   });
   if (__popc(mask) > MAX_CONTACTS) {   // keep the MAX_CONTACTS deepest (ties: lower primitive id)
     int keep = 0;
@@ -529,10 +530,24 @@ SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nst
 // only constants differ: they are picked per lane from the four legs' compile-time values
 // (identical values fold away).  Results go to the shared (LDS) context: per-leg articulated inertia /
 // bias contributions (summed by the leader), leg response, parked rows.
-template <typename T> SD T sel4(int L, double a, double b, double c, double d) {
-  if (a == b && b == c && c == d) return T(a);
-  return L == 0 ? T(a) : (L == 1 ? T(b) : (L == 2 ? T(c) : T(d)));
+// The legs are mirror images (L = 0 FL, 1 FR, 2 HL, 3 HR): a per-leg constant is +-v with the sign following
+// the front/hind (sx) and/or left/right (sy) reflection, so it is v times a per-lane sign instead of a lookup
+// (a 4-entry table made every use a dependent global load).  Irregular constants fall back to a blend.
+template <typename T> struct LegSign { T sx, sy, sxy, m1, m2, m3; };
+template <typename T> SD LegSign<T> leg_sign(int L) {
+  LegSign<T> g;
+  g.sx = (L & 2) ? T(-1) : T(1); g.sy = (L & 1) ? T(-1) : T(1); g.sxy = g.sx * g.sy;
+  g.m1 = L == 1 ? T(1) : T(0); g.m2 = L == 2 ? T(1) : T(0); g.m3 = L == 3 ? T(1) : T(0);
+  return g;
 }
+// SEL4: the four values must be constant expressions (a constexpr local forces compile-time evaluation --
+// reading the model through the `MD` reference at run time is a load chain through a global pointer)
+#define SEL4(T, g, A, B, C, D) ([&]() -> T { constexpr double a_ = (A), b_ = (B), c_ = (C), d_ = (D); \
+    if constexpr (a_ == b_ && b_ == c_ && c_ == d_) return T(a_); \
+    else if constexpr (b_ == -a_ && c_ == a_ && d_ == -a_) return T(a_) * (g).sy; \
+    else if constexpr (b_ == a_ && c_ == -a_ && d_ == -a_) return T(a_) * (g).sx; \
+    else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
+    else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
 template <typename T, int ROBOT, typename LDS, typename CH>
 SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds, int L) {
   SubCtx<T, ROBOT>& C = ch.get();
@@ -549,8 +564,9 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t 
     tau[k] = C.tau[L * NJ + k];
   }
   // value of link field f of joint k (or the foot, k = NJ) for this lane's leg
-#define LEGC(k, f) sel4<T>(L, RB::MD.links[1 + 0 * ST + (k)].f, RB::MD.links[1 + 1 * ST + (k)].f, \
-                           RB::MD.links[1 + 2 * ST + (k)].f, RB::MD.links[1 + 3 * ST + (k)].f)
+  const LegSign<T> lsg = leg_sign<T>(L);
+#define LEGC(k, f) SEL4(T, lsg, RB::MD.links[1 + 0 * ST + (k)].f, RB::MD.links[1 + 1 * ST + (k)].f, \
+                        RB::MD.links[1 + 2 * ST + (k)].f, RB::MD.links[1 + 3 * ST + (k)].f)
   RBI<T> Ik[NJ]; SV<T> pk[NJ]; SV<T> Sk[NJ], ck[NJ];
   {
     M3<T> Rp = R0;
@@ -661,8 +677,8 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t 
       const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
       const T pen = C.dist[p] + pp.slop;
       const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
-      const T fric = sel4<T>(L, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
-                             RB::MD.prims[18 + i].friction);
+      const T fric = SEL4(T, lsg, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
+                          RB::MD.prims[18 + i].friction);
       static_for<3>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
@@ -966,13 +982,13 @@ template <typename T> SD T team_sum16(T x) {
 // B~ = mu B) and every row is pre-scaled by 1/diag, so the sweep needs neither mu nor 1/diag:
 //   rec  [TR][4][38]   18 (J'_c, B~_c) pairs, one per accumulator component c (zero for the components of
 //                      other legs, so no masks in the loop) + 1 zero pair
-//   sca  [TR][4][2]    rhs', coupling c' with the slot partner (odd positions; 0 on even)
+//   sca  [TR][4]       rhs'
 //   lam  [TR][4]       impulses (warm start in, result out)
 template <typename T, typename LDS> struct TeamRows {
   static_assert(MAX_LIMITS == 2 && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
   static constexpr int NPOS0 = 2, FPOS0 = NPOS0 + MAX_CONTACTS;              // first normal / friction position
   static constexpr int NSLOT = 1 + MAX_CONTACTS / 2 + MAX_CONTACTS;          // 13
-  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 2, BC = 56;
+  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 1, BC = 56;
   static constexpr size_t off_rec = LDS::bytes(4);
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
@@ -1046,7 +1062,7 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
       T* q = rec + pos * (4 * TRW::REC); T* sc = sca + pos * (4 * TRW::SCA);
 #pragma unroll
       for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
-      sc[0] = T(0); sc[1] = T(0);
+      sc[0] = T(0);
       lam[pos * 4] = T(0);
     }
   }
@@ -1077,24 +1093,9 @@ SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
     for (int k = 12; k < TRW::REC; k++) q[k] = T(0);
     T* ql2 = q + 12 + 6 * leg;
     ql2[0] = c[6] * sJ; ql2[1] = c[15] * sB; ql2[2] = c[7] * sJ; ql2[3] = c[16] * sB; ql2[4] = c[8] * sJ; ql2[5] = c[17] * sB;
-    sc[0] = rhs / sB; sc[1] = T(0);     // finish_row's rhs already carries 1/diag
+    sc[0] = rhs / sB;                   // finish_row's rhs already carries 1/diag
     lam[pos * 4] = c[13];               // warm-start impulse (0 for friction / limit rows)
   }
-}
-
-// coupling of the two rows of a slot: c'_k = J'_{2k+1} . B~_{2k}   (lane k computes slot k; slots the sweep
-// skips hold stale rows -- their coupling is never read)
-template <typename T, typename LDS>
-SNI void phase_pair_coupling(const LDS lds, int t) {
-  using TRW = TeamRows<T, LDS>;
-  const int col = lds.lane;
-  if (t >= TRW::NSLOT) return;
-  const T* r0 = TRW::rec(col) + (2 * t) * (4 * TRW::REC);
-  const T* r1 = r0 + 4 * TRW::REC;
-  T c = T(0);
-#pragma unroll
-  for (int k = 0; k < 18; k++) c += r1[2 * k] * r0[2 * k + 1];
-  TRW::sca(col)[(2 * t + 1) * (4 * TRW::SCA) + 1] = c;
 }
 
 // exchange between the two 8-lane halves of a 16-lane team (values are uniform within a half)
@@ -1144,8 +1145,19 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
       const P2 u = ld2(rec_own + 2 * k * S_REC), v = ld2(rec_own + 2 * k * S_REC + dB), w = ld2(rec_own + 2 * k * S_REC + dC);
       J0[k] = u.x; B0[k] = u.y; J1[k] = v.x; B1[k] = v.y; J2[k] = w.x; B2[k] = w.y;
       X0[k] = ldT(rec_oth + 2 * k * S_REC + SZ); X1[k] = ldT(rec_oth + 2 * k * S_REC + dB + SZ); X2[k] = ldT(rec_oth + 2 * k * S_REC + dC + SZ);
-      const P2 s = ld2(sca_own + 2 * k * S_SCA);
-      rh[k] = s.x; cp[k] = s.y;
+      rh[k] = ldT(sca_own + 2 * k * S_SCA);
+      {   // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
+          // partner's B~ (both already in registers); half 0 takes 0 (its row does not wait for anybody)
+        T c = J0[k] * X0[k] + J1[k] * X1[k] + J2[k] * X2[k];
+        if constexpr (sizeof(T) == 4) {
+          c += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c), 0xB1, 0xF, 0xF, true));
+          c += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c), 0x4E, 0xF, 0xF, true));
+          c += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c), 0x141, 0xF, 0xF, true));
+        } else {
+          c += __shfl_xor(c, 1, 16); c += __shfl_xor(c, 2, 16); c += __shfl_xor(c, 4, 16);
+        }
+        cp[k] = half ? c : T(0);
+      }
       lm[k] = ldT(lam_own + 2 * k * S_LAM);
       // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
       const T lx = half_swap(lm[k]);
@@ -1210,6 +1222,16 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   }
 }
 
+// dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
+#ifdef SOLO_PHASE_TIMING
+__device__ unsigned long long solo_phase_cycles[16];
+#define SOLO_TICK(i) do { const long long now_ = clock64(); if (threadIdx.x == 0) atomicAdd(&solo_phase_cycles[i], (unsigned long long)(now_ - tick_)); tick_ = clock64(); } while (0)
+#define SOLO_TICK_INIT long long tick_ = clock64()
+#else
+#define SOLO_TICK(i) do {} while (0)
+#define SOLO_TICK_INIT do {} while (0)
+#endif
+
 template <typename T, int ROBOT, typename LDS> struct TeamCtx {
   using type = CtxLds<T, ROBOT, TeamRows<T, LDS>::off_ctx>;
   static constexpr size_t bytes = TeamRows<T, LDS>::off_ctx + 4 * sizeof(SubCtx<T, ROBOT>);
@@ -1222,15 +1244,20 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
   using TRW = TeamRows<T, LDS>;
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
   const CH ch{lds.lane};
+  SOLO_TICK_INIT;
   if (lead) phase_detect<T, ROBOT, CH>(ch, pp);
+  SOLO_TICK(0);
   if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);   // four legs on four lanes
+  SOLO_TICK(1);
   if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
+  SOLO_TICK(2);
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
-  phase_pair_coupling<T, LDS>(lds, t);
+  SOLO_TICK(3);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
+  SOLO_TICK(5);
   int mask = 0;
   if (lead) {
     SubCtx<T, ROBOT>& C = ch.get();
@@ -1251,6 +1278,7 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
     phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
     mask = C.mask;
   }
+  SOLO_TICK(6);
   return mask;
 }
 #endif  // !SOLO_HOST_SHIM

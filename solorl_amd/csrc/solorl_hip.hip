@@ -232,6 +232,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   constexpr int NQ = RB::NQ;
   using LDS = typename std::conditional<TEAM, RowLds<T, 4>, RowLds<T>>::type;
   constexpr int EPB = LDS::LANES;          // envs per workgroup: compile-time (LDS immediates)
+#ifdef SOLO_PHASE_TIMING
+  const long long kstart_ = clock64();
+#endif
   const int t = TEAM ? (threadIdx.x & 15) : 0;
   const int col = TEAM ? (threadIdx.x >> 4) : threadIdx.x;
   // team mode: a workgroup touches only 16 B of each state field, so eight consecutive workgroups share every
@@ -283,6 +286,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   if constexpr (TEAM) {
     using CH = typename TeamCtx<T, ROBOT, LDS>::type;
     const CH ch{col};
+#ifdef SOLO_PHASE_TIMING
+    if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
+#endif
     if (lead) ch.get().ps = E.ps;
 #pragma unroll 1
     for (int ss = 0; ss < P.frame_skip; ss++) {
@@ -295,6 +301,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       if (lead) E.mask = m;
     }
     if (lead) E.ps = ch.get().ps;
+#ifdef SOLO_PHASE_TIMING
+    if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[8], (unsigned long long)(clock64() - kstart_));
+#endif
   } else {
     SubCtx<T, ROBOT> C;
     C.ps = E.ps;
@@ -625,6 +634,14 @@ int check_cfg(const solorl_config* c) {
 extern "C" {
 
 const char* solorl_last_error(void) { return g_err.c_str(); }
+
+#ifdef SOLO_PHASE_TIMING
+int solorl_debug_phase_cycles(unsigned long long* out16, int reset) {   // dev builds only (tools/dev/phase_timing.py)
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(solo::solo_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_phase_cycles), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#endif
 
 int solorl_compute_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value,
                            float* returns, int T, int N, int use_gae, float gamma, float gae_lambda, int device_id,
