@@ -10,7 +10,7 @@ import torch  # noqa: F401
 from .config import SoloConfig, EnvState, InfoSoA
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libsolorl_hip.so")
+LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libsolorl_hip.so")   # SOLORL_LIB: dev A/B builds
 
 # every symbol include/solorl.h declares
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",

@@ -1106,20 +1106,42 @@ template <typename T> SD T half_swap(T x) {
 
 // Register-resident slot sweep.  Each 8-lane half of the team holds a full copy of the 18 accumulator
 // components (3 per lane); in slot k half 0 owns position 2k and half 1 position 2k+1, and every lane keeps
-// ITS row's J', B~, rhs' and impulse plus the partner row's B~ in VGPRs for the whole solve (the slot loops
-// are fully unrolled, so everything is statically indexed): the 50 sweeps never touch memory.  Both halves
-// reduce their own row's J'.acc at the same time against the pre-update accumulators; the Gauss-Seidel
-// dependency of position 2k+1 on 2k is restored analytically,
+// ITS row's J', B~, rhs' and impulse plus the partner row's B~ in VGPRs for the whole solve (everything is
+// statically indexed): the 50 sweeps never touch memory.  Both halves reduce their own row's J'.acc at the
+// same time against the pre-update accumulators; the Gauss-Seidel dependency of position 2k+1 on 2k is
+// restored analytically,
 //   J'_{2k+1}.(acc + B~_{2k} d0) = J'_{2k+1}.acc + c'_k d0,
-// a re-association of the same sums.  Slots are skipped on wave-uniform conditions (any limit row in the
-// wave; the wave's largest contact count), so teams with fewer rows sweep null rows.
-template <typename T, int ROBOT, typename LDS>
-SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
+// a re-association of the same sums.
+//
+// One instantiation per slot set of the wave (LIM: the limit slot, NNS normal slots, NFS friction slots; teams
+// with fewer rows sweep null rows), so the slot sequence -- each slot's predecessor and successor, with
+// wrap-around between sweeps -- is static.  A lone wavefront issues a DEPENDENT instruction only every
+// ~8.5 cycles (16 after a DPP move; tools/dev/ubench/issue.hip) and Gauss-Seidel is one long dependency
+// chain, so the chain is cut down to the scalar clamp: the J'.acc reduction of the NEXT slot (multiplies +
+// DPP butterfly, 2/3 of a slot's latency) is started one slot early on accumulators that lack the current
+// slot's update, which is added back analytically through two more precomputed couplings,
+//   J'_n.(acc + B~_own d_own + B~_oth d_oth) = J'_n.acc + eo_n d_own + ex_n d_oth,
+// and overlaps with the current slot's clamp chain.
+template <typename T> SD T team_red8(T x) {      // sum over the 8 lanes of a half (both halves at once)
+  if constexpr (sizeof(T) == 4) {
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  } else {
+    x += __shfl_xor(x, 1, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 4, 16);
+  }
+  return x;
+}
+
+template <typename T, typename LDS, int LIM, int NNS, int NFS>
+SNI void pgs_team_variant(int iterations, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
-  constexpr int LN = LDS::LANES, NS = TRW::NSLOT, NN = MAX_CONTACTS / 2, S_N0 = 1, S_F0 = 1 + NN;
+  constexpr int LN = LDS::LANES, n = LIM + NNS + NFS;
+  constexpr int S_N0 = 1, S_F0 = 1 + MAX_CONTACTS / 2;      // slot numbers of the first normal / friction slot
+  static_assert(n >= 1, "empty sweeps are not instantiated");
+  // sweep order i = 0..n-1 -> slot number (position pair) in the team records
+  struct Ord { static constexpr int slot(int i) { return i < LIM ? 0 : (i < LIM + NNS ? S_N0 + (i - LIM) : S_F0 + (i - LIM - NNS)); } };
   const int col = lds.lane;
-  int nlt, nc, ncmax, anylim;
-  team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
   const int h = t & 7, half = t >> 3;
   const int cc = h < 2 ? 16 + h : 18;           // third accumulator component (or the zero pair)
   constexpr int SZ = (int)sizeof(T);
@@ -1133,86 +1155,79 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
   const int rec_oth = rec_own + (1 - 2 * half) * S_REC;
   const int sca_own = (int)TRW::off_sca + col * TRW::SCA * SZ + half * S_SCA;
   const int lam_own = (int)TRW::off_lam + col * SZ + half * S_LAM;
-  T J0[NS], J1[NS], J2[NS], B0[NS], B1[NS], B2[NS], X0[NS], X1[NS], X2[NS], rh[NS], cp[NS], lm[NS];
-  T lmx[NN];                                    // the partner half's impulse of the normal slots (friction bounds)
+  // all arrays below are indexed by the sweep index i
+  T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
+  T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
   T a0 = T(0), a1 = T(0), a2 = T(0);
-  auto live = [&](int k) -> bool { return k < S_N0 ? anylim != 0 : (k < S_F0 ? 2 * (k - S_N0) < ncmax : (k - S_F0) < ncmax); };
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    J0[k] = J1[k] = J2[k] = B0[k] = B1[k] = B2[k] = X0[k] = X1[k] = X2[k] = rh[k] = cp[k] = lm[k] = T(0);
-    if (k >= S_N0 && k < S_F0) lmx[k - S_N0] = T(0);
-    if (live(k)) {
-      const P2 u = ld2(rec_own + 2 * k * S_REC), v = ld2(rec_own + 2 * k * S_REC + dB), w = ld2(rec_own + 2 * k * S_REC + dC);
-      J0[k] = u.x; B0[k] = u.y; J1[k] = v.x; B1[k] = v.y; J2[k] = w.x; B2[k] = w.y;
-      X0[k] = ldT(rec_oth + 2 * k * S_REC + SZ); X1[k] = ldT(rec_oth + 2 * k * S_REC + dB + SZ); X2[k] = ldT(rec_oth + 2 * k * S_REC + dC + SZ);
-      rh[k] = ldT(sca_own + 2 * k * S_SCA);
-      {   // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
-          // partner's B~ (both already in registers); half 0 takes 0 (its row does not wait for anybody)
-        T c = J0[k] * X0[k] + J1[k] * X1[k] + J2[k] * X2[k];
-        if constexpr (sizeof(T) == 4) {
-          c += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c), 0xB1, 0xF, 0xF, true));
-          c += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c), 0x4E, 0xF, 0xF, true));
-          c += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(c), 0x141, 0xF, 0xF, true));
-        } else {
-          c += __shfl_xor(c, 1, 16); c += __shfl_xor(c, 2, 16); c += __shfl_xor(c, 4, 16);
-        }
-        cp[k] = half ? c : T(0);
-      }
-      lm[k] = ldT(lam_own + 2 * k * S_LAM);
-      // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
-      const T lx = half_swap(lm[k]);
-      if (k >= S_N0 && k < S_F0) lmx[k - S_N0] = lx;
-      a0 += B0[k] * lm[k] + X0[k] * lx; a1 += B1[k] * lm[k] + X1[k] * lx; a2 += B2[k] * lm[k] + X2[k] * lx;
-    }
-  }
-  // one slot: bounds [lo, hi] = [0, inf) for unilateral rows, [-hi, hi] for the friction rows of a contact
-  auto slot = [&](int k, bool fric, T hi, T& delx_out) {
-    T d = J0[k] * a0 + J1[k] * a1 + J2[k] * a2;       // 8-lane butterfly: both halves reduce their own row at once
-    if constexpr (sizeof(T) == 4) {
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
-    } else {
-      d += __shfl_xor(d, 1, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 4, 16);
-    }
-    auto clampb = [&](T x) -> T {
-      if (!fric) return x > T(0) ? x : T(0);
-      if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, -hi, hi);
-      else return x < -hi ? -hi : (x > hi ? hi : x);
-    };
-    T sp = (lm[k] + rh[k]) - d;
-    // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
-    // (cp = 0 in half 0, whose second clamp therefore repeats the first)
-    const T dfirst = clampb(sp) - lm[k];
-    sp -= cp[k] * half_swap(dfirst);
-    const T s = clampb(sp);
-    const T del = s - lm[k];
-    lm[k] = s;
-    const T delx = half_swap(del);
-    a0 += B0[k] * del + X0[k] * delx;
-    a1 += B1[k] * del + X1[k] * delx;
-    a2 += B2[k] * del + X2[k] * delx;
-    delx_out = delx;
-  };
+  static_for<n>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int k = Ord::slot(i);
+    const P2 u = ld2(rec_own + 2 * k * S_REC), v = ld2(rec_own + 2 * k * S_REC + dB), w = ld2(rec_own + 2 * k * S_REC + dC);
+    J0[i] = u.x; B0[i] = u.y; J1[i] = v.x; B1[i] = v.y; J2[i] = w.x; B2[i] = w.y;
+    X0[i] = ldT(rec_oth + 2 * k * S_REC + SZ); X1[i] = ldT(rec_oth + 2 * k * S_REC + dB + SZ); X2[i] = ldT(rec_oth + 2 * k * S_REC + dC + SZ);
+    rh[i] = ldT(sca_own + 2 * k * S_SCA);
+    // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
+    // partner's B~; half 0 takes 0 (its row does not wait for anybody)
+    const T c = team_red8(J0[i] * X0[i] + J1[i] * X1[i] + J2[i] * X2[i]);
+    cp[i] = half ? c : T(0);
+    lm[i] = ldT(lam_own + 2 * k * S_LAM);
+    // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
+    const T lx = half_swap(lm[i]);
+    if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx;
+    a0 += B0[i] * lm[i] + X0[i] * lx; a1 += B1[i] * lm[i] + X1[i] * lx; a2 += B2[i] * lm[i] + X2[i] * lx;
+  });
+  // couplings with the predecessor slot (wrapping around: the first slot follows the last one of the previous sweep)
+  static_for<n>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, p = (i + n - 1) % n;
+    eo[i] = team_red8(J0[i] * B0[p] + J1[i] * B1[p] + J2[i] * B2[p]);
+    ex[i] = team_red8(J0[i] * X0[p] + J1[i] * X1[p] + J2[i] * X2[p]);
+  });
+  T dpre = team_red8(J0[0] * a0 + J1[0] * a1 + J2[0] * a2);
+  T delp = T(0), delxp = T(0);
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
-    T dx;
-    if (anylim) slot(0, false, T(0), dx);
-#pragma unroll
-    for (int m = 0; m < NN; m++)
-      if (2 * m < ncmax) { slot(S_N0 + m, false, T(0), dx); lmx[m] += dx; }
-#pragma unroll
-    for (int k = 0; k < MAX_CONTACTS; k++)
-      if (k < ncmax) {
-        const T hi = (half == (k & 1)) ? lm[S_N0 + (k >> 1)] : lmx[k >> 1];     // impulse of contact k's normal row
-        slot(S_F0 + k, true, hi, dx);
+    static_for<n>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, in = (i + 1) % n;
+      constexpr bool fric = i >= LIM + NNS;
+      // next slot's reduction on the accumulators as they are now (without this slot's update)
+      const T dnext = team_red8(J0[in] * a0 + J1[in] * a1 + J2[in] * a2);
+#ifdef SOLO_PGS_NOPIPE    // dev check: plain in-order reduction
+      const T d = team_red8(J0[i] * a0 + J1[i] * a1 + J2[i] * a2);
+#else
+      const T d = dpre + eo[i] * delp + ex[i] * delxp;
+#endif
+      T hi = T(0);
+      if constexpr (fric) {   // impulse of this contact's normal row: normal slot c/2, half c&1
+        constexpr int c = i - LIM - NNS;
+        hi = (half == (c & 1)) ? lm[LIM + (c >> 1)] : lmo[c >> 1];
       }
+      auto clampb = [&](T x) -> T {
+        if constexpr (!fric) return x > T(0) ? x : T(0);
+        else if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, -hi, hi);
+        else return x < -hi ? -hi : (x > hi ? hi : x);
+      };
+      T sp = (lm[i] + rh[i]) - d;
+      // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
+      // (cp = 0 in half 0, whose second clamp therefore repeats the first)
+      const T dfirst = clampb(sp) - lm[i];
+      sp -= cp[i] * half_swap(dfirst);
+      const T sv = clampb(sp);
+      const T del = sv - lm[i];
+      lm[i] = sv;
+      const T delx = half_swap(del);
+      if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] += delx;
+      a0 += B0[i] * del + X0[i] * delx;
+      a1 += B1[i] * del + X1[i] * delx;
+      a2 += B2[i] * del + X2[i] * delx;
+      dpre = dnext; delp = del; delxp = delx;
+    });
   }
   // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
   if (h == 0) {
-#pragma unroll
-    for (int k = 0; k < NS; k++)
-      if (live(k)) *reinterpret_cast<T*>(solo_smem + lam_own + 2 * k * S_LAM) = lm[k];
+    static_for<n>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      *reinterpret_cast<T*>(solo_smem + lam_own + 2 * Ord::slot(i) * S_LAM) = lm[i];
+    });
   }
   T* const hdr = lds.hdr();
   if (half == 0) {
@@ -1220,6 +1235,38 @@ SNI void phase_pgs_team(int iterations, const LDS lds, int t) {
     lds.y()[(h + 2) * LN] = a1;
     if (h < 2) lds.y()[(10 + h) * LN] = a2;
   }
+}
+
+template <typename T, int ROBOT, typename LDS>
+SD void phase_pgs_team(int iterations, const LDS lds, int t) {
+  constexpr int LN = LDS::LANES;
+  int nlt, nc, ncmax, anylim;
+  team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
+#define SOLO_SWEEP_L(N_, F_) do { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_>(iterations, lds, t); \
+                                  else pgs_team_variant<T, LDS, 0, N_, F_>(iterations, lds, t); } while (0)
+  switch (ncmax) {       // wave-uniform
+    case 0:
+      if (anylim) pgs_team_variant<T, LDS, 1, 0, 0>(iterations, lds, t);
+      else {             // no rows at all: the accumulators the leader reads back are zero
+        const int h = t & 7;
+        T* const hdr = lds.hdr();
+        if ((t >> 3) == 0) {
+          if (h < 6) hdr[(2 + h) * LN] = T(0); else lds.y()[(h - 6) * LN] = T(0);
+          lds.y()[(h + 2) * LN] = T(0);
+          if (h < 2) lds.y()[(10 + h) * LN] = T(0);
+        }
+      }
+      break;
+    case 1: SOLO_SWEEP_L(1, 1); break;
+    case 2: SOLO_SWEEP_L(1, 2); break;
+    case 3: SOLO_SWEEP_L(2, 3); break;
+    case 4: SOLO_SWEEP_L(2, 4); break;
+    case 5: SOLO_SWEEP_L(3, 5); break;
+    case 6: SOLO_SWEEP_L(3, 6); break;
+    case 7: SOLO_SWEEP_L(4, 7); break;
+    default: SOLO_SWEEP_L(4, 8); break;
+  }
+#undef SOLO_SWEEP_L
 }
 
 // dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
