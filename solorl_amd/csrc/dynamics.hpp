@@ -299,7 +299,8 @@ SD void park_row(const LDS& lds, int slot, SV<T> f0, const T (&JL)[3], const T (
 
 // ---------------------------------------------------------------- phase 1: collision detection
 // start-of-step pose (K1, K6'): support points, contact mask, MAX_CONTACTS cap, row counts
-template <typename T, int ROBOT, typename CH>
+// SINCOS_DONE: C.sn / C.cs were already filled (team mode: one joint per lane, substep_team)
+template <typename T, int ROBOT, typename CH, bool SINCOS_DONE = false>
 SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
@@ -309,7 +310,10 @@ SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
   C.R0 = R0;
   T sn[NQ], cs[NQ];
 #pragma unroll
-  for (int j = 0; j < NQ; j++) { sincos_t(st.q[j], sn[j], cs[j]); C.sn[j] = sn[j]; C.cs[j] = cs[j]; }
+  for (int j = 0; j < NQ; j++) {
+    if constexpr (SINCOS_DONE) { sn[j] = C.sn[j]; cs[j] = C.cs[j]; }
+    else { sincos_t(st.q[j], sn[j], cs[j]); C.sn[j] = sn[j]; C.cs[j] = cs[j]; }
+  }
   T dist[NPRIM];
   int mask = 0;
   static_for<12>([&](auto pc) {
@@ -703,9 +707,9 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t 
 // ---------------------------------------------------------------- phase 3: base solve + finish rows
 // base_solve: parks the base primitives' rows, inverts the base articulated inertia, computes the
 // unconstrained velocities u* = u + dt*udot (C.ub, C.qds) and returns Lam and the padded leg rates.
-template <typename T, int ROBOT, typename LDS>
+template <typename T, int ROBOT, typename LDS, bool TEAMQ = false, typename QOUT>
 SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS& lds,
-                   Sym6<T>& Lam, T (&qsl)[4][3]) {
+                   Sym6<T>& Lam, QOUT& qsl) {   // QOUT: T[4][3] padded leg rates, or (TEAMQ) SV<T> receiving a0
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   const T dt = pp.dt;
@@ -738,18 +742,21 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
   // base acceleration (gravity via the accelerating-frame trick), u* = u + dt*udot
   Lam = spd_inverse(C.Ibase);
   const SV<T> a0 = mul(Lam, C.pbase) * T(-1);
-  static_for<4>([&](auto lc) {
-    constexpr int L = decltype(lc)::value;
+  if constexpr (TEAMQ) qsl = a0;
+  else {
+    static_for<4>([&](auto lc) {
+      constexpr int L = decltype(lc)::value;
 #pragma unroll
-    for (int k = 0; k < NJ; k++) {
-      T qdd = C.LR[L].qdd0[k] - dot(C.LR[L].G[k], a0);
-      C.qds[L * NJ + k] = clampv(C.ps.qd[L * NJ + k] + dt * qdd, pp.vmax);
-    }
-  });
+      for (int k = 0; k < NJ; k++) {
+        T qdd = C.LR[L].qdd0[k] - dot(C.LR[L].G[k], a0);
+        C.qds[L * NJ + k] = clampv(C.ps.qd[L * NJ + k] + dt * qdd, pp.vmax);
+      }
+    });
 #pragma unroll
-  for (int L = 0; L < 4; L++)
+    for (int L = 0; L < 4; L++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) qsl[L][k] = k < NJ ? C.qds[L * NJ + k] : T(0);
+      for (int k = 0; k < 3; k++) qsl[L][k] = k < NJ ? C.qds[L * NJ + k] : T(0);
+  }
   const V3<T> bw = C.ps.w, bv = C.ps.v;
   V3<T> vdot = a0.l + cross(bw, bv); vdot.z -= pp.gravity;
   SV<T> ub;
@@ -988,7 +995,7 @@ template <typename T, typename LDS> struct TeamRows {
   static_assert(MAX_LIMITS == 2 && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
   static constexpr int NPOS0 = 2, FPOS0 = NPOS0 + MAX_CONTACTS;              // first normal / friction position
   static constexpr int NSLOT = 1 + MAX_CONTACTS / 2 + MAX_CONTACTS;          // 13
-  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 1, BC = 56;
+  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 1, BC = 60;
   static constexpr size_t off_rec = LDS::bytes(4);
   static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
   static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
@@ -998,13 +1005,14 @@ template <typename T, typename LDS> struct TeamRows {
   SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + pos*4*REC
   SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + pos*4*SCA
   SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + pos*4
-  SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12
+  SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12, a0 6
   SD static int pos_of(int r, int nlt, int nc) {   // solver row index -> position
     return r < nlt ? r : (r < nlt + nc ? NPOS0 + (r - nlt) : FPOS0 + (r - nlt - nc));
   }
 };
 
-// leader: base solve, then publish what the row-finishing lanes need
+// leader: base solve, then publish what the other lanes need (bc: Lam 36, u*_base 6, padded leg rates 12, -a0 6... see TeamRows)
+// TEAMQ = true: the leg rates u*_leg (C.qds, bc[42..]) are left to phase_legrates_team (one joint per lane).
 template <typename T, int ROBOT, typename LDS, typename CH>
 SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
@@ -1016,20 +1024,37 @@ SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size
     for (int L = 0; L < 4; L++) { add(Ib, C.Ileg[L]); pb = pb + C.pleg[L]; }
     C.Ibase = Ib; C.pbase = pb;
   }
-  Sym6<T> Lam; T qsl[4][3];
-  base_solve<T, ROBOT, LDS>(C, pp, lam_prev, nstride, lds, Lam, qsl);
+  Sym6<T> Lam; SV<T> a0;
+  base_solve<T, ROBOT, LDS, true>(C, pp, lam_prev, nstride, lds, Lam, a0);
   T* bc = TRW::bc(lds.lane);
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
     for (int j = 0; j < 6; j++) bc[i * 6 + j] = Lam.m[i][j];
   bc[36] = C.ub.a.x; bc[37] = C.ub.a.y; bc[38] = C.ub.a.z; bc[39] = C.ub.l.x; bc[40] = C.ub.l.y; bc[41] = C.ub.l.z;
-#pragma unroll
-  for (int L = 0; L < 4; L++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) bc[42 + L * 3 + k] = qsl[L][k];
+  bc[54] = a0.a.x; bc[55] = a0.a.y; bc[56] = a0.a.z; bc[57] = a0.l.x; bc[58] = a0.l.y; bc[59] = a0.l.z;
   T* hdr = lds.hdr();
   hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
+}
+
+// unconstrained leg rates u*_leg = qd + dt (qdd0 - G.a0), clamped: joint t on lane t (padded copy for the rows)
+template <typename T, int ROBOT, typename LDS, typename CH>
+SD void phase_legrates_team(CH ch, const PhysParams<T>& pp, const LDS lds, int t) {
+  using RB = Robot<ROBOT>;
+  using TRW = TeamRows<T, LDS>;
+  constexpr int NJ = RB::NJ;
+  T* bc = TRW::bc(lds.lane);
+  if (t < RB::NQ) {
+    SubCtx<T, ROBOT>& C = ch.get();
+    const int L = t / NJ, k = t - L * NJ;
+    const SV<T> a0{{bc[54], bc[55], bc[56]}, {bc[57], bc[58], bc[59]}};
+    const T qdd = C.LR[L].qdd0[k] - dot(C.LR[L].G[k], a0);
+    const T v = clampv(C.ps.qd[t] + pp.dt * qdd, pp.vmax);
+    C.qds[t] = v;
+    bc[42 + L * 3 + k] = v;
+  } else if (NJ < 3 && t < 12) {          // Solo8: third (absent) joint of each leg
+    if ((t - RB::NQ) < 4) bc[42 + (t - RB::NQ) * 3 + 2] = T(0);
+  }
 }
 
 // this team's row counts and the wave-uniform sweep extent (every team of the wave sweeps the same slots)
@@ -1269,6 +1294,51 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
 #undef SOLO_SWEEP_L
 }
 
+// apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.
+// Reads the sweep's results straight from the team arrays (accumulators in hdr / y, impulses in lam).
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS lds, int t, bool valid,
+                              bool lead) {
+  using RB = Robot<ROBOT>;
+  using TRW = TeamRows<T, LDS>;
+  constexpr int NJ = RB::NJ, LN = LDS::LANES;
+  if (!valid) return;
+  SubCtx<T, ROBOT>& C = ch.get();
+  const T dt = pp.dt;
+  const int mask = C.mask;
+  const T* lam = TRW::lam(lds.lane);
+  for (int p = t; p < NPRIM; p += 16) {       // warm-start cache: normal impulse of primitive p (its rank among the contacts)
+    const T l = ((mask >> p) & 1) ? lam[(TRW::NPOS0 + __popc(mask & ((1 << p) - 1))) * 4] : T(0);
+    lam_prev[(size_t)p * nstride] = l;
+  }
+  const T* hdr = lds.hdr();
+  const SV<T> w{{hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]}, {hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]}};
+  if (t < RB::NQ) {
+    const int L = t / NJ, k = t - L * NJ;
+    const T nv = clampv(C.qds[t] + lds.y()[(L * 3 + k) * LN] - dot(C.LR[L].G[k], w), pp.vmax);
+    C.ps.qd[t] = nv;
+    C.ps.q[t] += dt * nv;
+  }
+  if (lead) {
+    const SV<T> ub = C.ub;
+    const V3<T> nw = mk(clampv(ub.a.x + w.a.x, pp.vmax), clampv(ub.a.y + w.a.y, pp.vmax), clampv(ub.a.z + w.a.z, pp.vmax));
+    const V3<T> nv = mk(clampv(ub.l.x + w.l.x, pp.vmax), clampv(ub.l.y + w.l.y, pp.vmax), clampv(ub.l.z + w.l.z, pp.vmax));
+    C.ps.w = nw; C.ps.v = nv;
+    C.ps.pos = fma3(nv, dt, C.ps.pos);
+    T wn2 = dot(nw, nw), wn = sqrt(wn2), sc, s_, cw;
+    sincos_t(T(0.5) * wn * dt, s_, cw);
+    if (wn < T(1e-3)) sc = T(0.5) * dt - dt * dt * dt * T(1.0 / 48.0) * wn2; else sc = s_ / wn;
+    T ax = nw.x * sc, ay = nw.y * sc, az = nw.z * sc;
+    T x = C.ps.qx, yq = C.ps.qy, z = C.ps.qz, ww = C.ps.qw;
+    T nx = cw * x + ax * ww + ay * z - az * yq;
+    T ny = cw * yq - ax * z + ay * ww + az * x;
+    T nz = cw * z + ax * yq - ay * x + az * ww;
+    T nq = cw * ww - ax * x - ay * yq - az * z;
+    T inv = T(1) / sqrt(nx * nx + ny * ny + nz * nz + nq * nq);
+    C.ps.qx = nx * inv; C.ps.qy = ny * inv; C.ps.qz = nz * inv; C.ps.qw = nq * inv;
+  }
+}
+
 // dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
 #ifdef SOLO_PHASE_TIMING
 __device__ unsigned long long solo_phase_cycles[16];
@@ -1292,7 +1362,13 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
   const CH ch{lds.lane};
   SOLO_TICK_INIT;
-  if (lead) phase_detect<T, ROBOT, CH>(ch, pp);
+  if (valid && t < Robot<ROBOT>::NQ) {   // sin/cos of joint t on lane t
+    SubCtx<T, ROBOT>& C = ch.get();
+    T sn, cs;
+    sincos_t(C.ps.q[t], sn, cs);
+    C.sn[t] = sn; C.cs[t] = cs;
+  }
+  if (lead) phase_detect<T, ROBOT, CH, true>(ch, pp);
   SOLO_TICK(0);
   if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);   // four legs on four lanes
   SOLO_TICK(1);
@@ -1300,33 +1376,15 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
   else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
+  if (valid) phase_legrates_team<T, ROBOT, LDS, CH>(ch, pp, lds, t);
   SOLO_TICK(2);
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
   SOLO_TICK(3);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
   SOLO_TICK(5);
-  int mask = 0;
-  if (lead) {
-    SubCtx<T, ROBOT>& C = ch.get();
-    const T* hdr = lds.hdr();
-    C.w.a = mk(hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]); C.w.l = mk(hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]);
-#pragma unroll
-    for (int l = 0; l < 4; l++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) C.y[l][k] = lds.y()[(l * 3 + k) * LN];
-    const T* lam = TRW::lam(lds.lane);
-    // impulses back into the lane-layout aux (phase_integrate reads the base primitives' there)
-    for (int k = 0; k < C.nc; k++) lds.A(C.nlim_total + k, LDS::A_LAM) = lam[(TRW::NPOS0 + k) * 4];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int p = 12 + i;
-      C.lam_n[i] = ((C.mask >> p) & 1) ? lam[(TRW::NPOS0 + __popc(C.mask & ((1 << p) - 1))) * 4] : T(0);
-    }
-    phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-    mask = C.mask;
-  }
+  phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
   SOLO_TICK(6);
-  return mask;
+  return lead ? ch.get().mask : 0;
 }
 #endif  // !SOLO_HOST_SHIM
 

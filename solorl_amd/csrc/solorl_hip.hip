@@ -375,9 +375,21 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   if (out.dr4) out.dr4[env] = (float)E.dr[4];
 
   // ---- auto-reset (agents/ppo/envs.py:39) and observation
+#ifdef SOLO_PHASE_TIMING
+  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[9], (unsigned long long)(clock64() - kstart_));
+#endif
   if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, env, snf, sni, M, P);
+#ifdef SOLO_PHASE_TIMING
+  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[10], (unsigned long long)(clock64() - kstart_));
+#endif
   write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, env, P.task, out.obs);
+#ifdef SOLO_PHASE_TIMING
+  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[11], (unsigned long long)(clock64() - kstart_));
+#endif
   store_env(E, sf, si, L, (size_t)N, e);
+#ifdef SOLO_PHASE_TIMING
+  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[12], (unsigned long long)(clock64() - kstart_));
+#endif
 }
 
 template <typename T, int ROBOT>
@@ -560,6 +572,7 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
     dim3 grid((((N + 3) / 4) + 7) & ~7), block(64);      // multiple of 8: XCD-contiguous env ranges (step_body)
     using TeamLds = RowLds<T, 4>;
     const size_t team_smem = TeamCtx<T, ROBOT, TeamLds>::bytes;
+    static_assert(sizeof(T) == 8 || TeamCtx<T, ROBOT, TeamLds>::bytes <= 40960, "team-mode LDS must allow 4 workgroups per CU");
     hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
                        make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
     HIP_TRY(hipGetLastError());
