@@ -1262,11 +1262,17 @@ SNI void pgs_team_variant(int iterations, const LDS lds, int t) {
   }
 }
 
+#ifdef SOLO_PHASE_TIMING
+__device__ unsigned long long solo_pgs_cycles[2][10];     // [cycles | calls][wave's largest contact count]
+#endif
 template <typename T, int ROBOT, typename LDS>
 SD void phase_pgs_team(int iterations, const LDS lds, int t) {
   constexpr int LN = LDS::LANES;
   int nlt, nc, ncmax, anylim;
   team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
+#ifdef SOLO_PHASE_TIMING
+  const long long pgs_t0_ = clock64();
+#endif
 #define SOLO_SWEEP_L(N_, F_) do { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_>(iterations, lds, t); \
                                   else pgs_team_variant<T, LDS, 0, N_, F_>(iterations, lds, t); } while (0)
   switch (ncmax) {       // wave-uniform
@@ -1292,6 +1298,12 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
     default: SOLO_SWEEP_L(4, 8); break;
   }
 #undef SOLO_SWEEP_L
+#ifdef SOLO_PHASE_TIMING
+  if (threadIdx.x == 0) {
+    atomicAdd(&solo_pgs_cycles[0][ncmax], (unsigned long long)(clock64() - pgs_t0_));
+    atomicAdd(&solo_pgs_cycles[1][ncmax], 1ull);
+  }
+#endif
 }
 
 // apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.

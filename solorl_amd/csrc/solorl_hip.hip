@@ -654,6 +654,11 @@ int solorl_debug_phase_cycles(unsigned long long* out16, int reset) {   // dev b
   if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_phase_cycles), z, sizeof(z)) != hipSuccess) return -3; }
   return 0;
 }
+int solorl_debug_pgs_cycles(unsigned long long* out20, int reset) {
+  if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(solo::solo_pgs_cycles), 20 * sizeof(unsigned long long)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[20] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_pgs_cycles), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
 #endif
 
 int solorl_compute_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value,
@@ -711,7 +716,7 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     if (const char* ev = getenv("SOLORL_ENVS_PER_WAVE")) { int v = atoi(ev); if (v >= 1 && v <= 64) epw = v; }
     if (h->f64 && epw > 32) epw = 32;
     if (const char* ev = getenv("SOLORL_SPREAD")) h->spread = atoi(ev) != 0;
-    h->team = num_envs <= 8192;
+    h->team = true;   // measured (tools/dev/bench_n.py): team mode wins at every batch size, 1k .. 262k envs; lane mode: SOLORL_TEAM=0
     if (const char* ev = getenv("SOLORL_TEAM")) h->team = atoi(ev) != 0;
     h->epw = epw;
   }

@@ -293,3 +293,40 @@ def test_fused_returns_kernel_matches_reference_golden(gpu_device):
         getattr(cpu, k).copy_(getattr(big, k).cpu())
     cpu.compute_returns(nv.cpu(), True, 0.99, 0.95)
     assert torch.allclose(big.returns[:-1].cpu(), cpu.returns[:-1], atol=2e-4, rtol=1e-4)
+
+
+def test_lane_mode_sorting_and_team_mode_agree(gpu_device):
+    """The three execution layouts of the same physics: team mode (16 lanes per env, default), lane mode
+    (one env per lane, SOLORL_TEAM=0) and contact-count-sorted storage (SOLORL_SORT=1).  Sorting only permutes
+    storage: bitwise neutral in lane mode; in team mode an env's sweep is specialised on the slot set of its
+    wavefront (null rows, other predecessor slots), so like lane vs team it is a re-association of the same sums."""
+    from solorl_amd.vec_env import SoloVecEnv
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    N = 512
+    g = torch.Generator(device="cuda:0"); g.manual_seed(11)
+    acts = 0.5 * (torch.rand((8, N, 12), device="cuda:0", generator=g) * 2 - 1)
+
+    def run(**envvars):
+        old = {k: os.environ.get(k) for k in envvars}
+        os.environ.update({k: str(v) for k, v in envvars.items()})
+        try:
+            env = SoloVecEnv(c, N, device="cuda:0", seed=3)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        o = env.reset()
+        qs = []
+        for t in range(8):
+            o, r, d, _ = env.step_inplace(acts[t])
+            qs.append(o.clone())
+        return torch.stack(qs)
+
+    team = run(SOLORL_TEAM=1, SOLORL_SORT=0)
+    team_sorted = run(SOLORL_TEAM=1, SOLORL_SORT=1)
+    lane = run(SOLORL_TEAM=0, SOLORL_SORT=0)
+    lane_sorted = run(SOLORL_TEAM=0, SOLORL_SORT=1)
+    assert torch.equal(lane, lane_sorted)
+    for other in (team_sorted, lane):
+        d = (team - other).abs()[:, :, 16:28]     # joint angles / 10 rad: the north-star quantity
+        assert d.median().item() * 10 < 1e-5 and torch.quantile(d.flatten(), 0.9).item() * 10 < 1e-3

@@ -22,6 +22,8 @@ torch.cuda.synchronize()
 L = _native.lib()
 buf = (C.c_ulonglong * 16)()
 L.solorl_debug_phase_cycles(buf, 1)
+pg = (C.c_ulonglong * 20)()
+L.solorl_debug_pgs_cycles(pg, 1)
 K = 100
 for t in range(K): env.step_inplace(a[t % 16])
 torch.cuda.synchronize()
@@ -34,3 +36,10 @@ for i, n in enumerate(names):
     if i < 7: tot += per
     print("%-38s %10.0f cycles/step/wave  (%.1f us at 2.4 GHz)" % (n, per, per / 2400.0))
 print("sum of substep phases %.0f cycles/step/wave" % tot)
+L.solorl_debug_pgs_cycles(pg, 0)
+print("PGS per call by the wave's largest contact count (50 sweeps):")
+for c in range(10):
+    if pg[10 + c]:
+        slots = (c + 1) // 2 + c
+        print("  ncmax %d: %6.2f %% of calls, %8.0f cycles/call, %6.1f cycles/sweep, %5.1f cycles/slot (%d slots, no limit slot)" % (
+            c, 100.0 * pg[10 + c] / sum(pg[10:20]), pg[c] / pg[10 + c], pg[c] / pg[10 + c] / 50, pg[c] / pg[10 + c] / 50 / max(slots, 1), slots))
