@@ -169,11 +169,19 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "step_kernel_team<float,solo12>", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
                          "algorithmic_bytes_per_env_step": bytes_step,
-                         "note": "path is FP32-VALU/latency bound (SURVEY 8d); HBM fraction is small by construction"},
+                         "note": "path is FP32-VALU issue / dependency bound (SURVEY 8d), see valu_issue; HBM fraction is small by construction"},
         }
         traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(traffic_file):   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            out["roofline"]["traffic"] = json.load(open(traffic_file))["bytes_per_launch"]
+            prof = json.load(open(traffic_file))
+            out["roofline"]["traffic"] = prof["bytes_per_launch"]
+            if "valu_insts_per_launch" in prof:
+                # what actually bounds the kernel: VALU issue.  A SIMD issues one wave64 VALU instruction per 4 cycles
+                # (MI355X_MICROARCH.md: 256 CUs x 4 SIMD16); instruction count from the committed SQ_INSTS_VALU pass.
+                peak = 256 * 4 * 2.4e9 / 4.0
+                rate = prof["valu_insts_per_launch"] / (k_avg * 1e-3)
+                out["roofline"]["valu_issue"] = {"achieved_ginst_s": rate / 1e9, "peak_ginst_s": peak / 1e9, "frac": rate / peak,
+                                                 "valu_insts_per_launch": prof["valu_insts_per_launch"]}
         if ppo is not None:
             out["ppo_loop"] = ppo
         if world == 1 and not args.no_cpu_baseline:
