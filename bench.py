@@ -59,32 +59,38 @@ def cpu_baseline(cfg, budget_s=12.0):
 
 def ppo_leg(env, dev, world, T):
     """One PPO iteration with the README hyper-parameters (lr 2.5e-4, entropy 0.01, clip 0.1, GAE,
-    ppo-epoch 5 scaled to 1 epoch here, 50 mini-batches): rollout of T steps + returns + update."""
+    ppo-epoch 5 scaled to 1 epoch here, 50 mini-batches): rollout of T steps + returns + update, both loops
+    replayed from HIP graphs (solorl_amd/ppo/graphs.py) that were captured in an untimed first iteration."""
     import torch
-    from solorl_amd.ppo import Policy, PPO, RolloutStorage
-    from solorl_amd.ppo.train import rollout
+    from solorl_amd.ppo import Policy, RolloutStorage
+    from solorl_amd.ppo.graphs import GraphedPPO, GraphedRollout
     N = env.nenvs
     torch.manual_seed(1)
     pol = Policy(env.observation_space.shape, env.action_space, None, {"hidden_size": 64}).to(dev)
-    agent = PPO(pol, 0.1, 1, max(T * N // 50, 1), 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
+    agent = GraphedPPO(pol, 0.1, 1, max(T * N // 50, 1), 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
     st = RolloutStorage(T, N, env.observation_space.shape, env.act_dim, dev)
     st.obs[0].copy_(env.get_observation())
-    wst = RolloutStorage(8, N, env.observation_space.shape, env.act_dim, dev)   # warm-up: rollout + one tiny update
-    wst.obs[0].copy_(env.get_observation())                                       # (first-call library initialisation)
-    rollout(env, pol, wst, 8)
-    wst.compute_returns(pol.get_value(wst.obs[-1]).detach(), True, 0.99, 0.95)
-    PPO(pol, 0.1, 1, 8 * N // 4, 0.5, 0.01, lr=1e-9, max_grad_norm=0.5).update(wst)
-    st.obs[0].copy_(env.get_observation())
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    rollout(env, pol, st, T)
-    torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
     with torch.no_grad():
-        nv = pol.get_value(st.obs[-1])
-    st.compute_returns(nv, True, 0.99, 0.95)
-    agent.update(st)
-    torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+        pol.act(st.obs[0]); pol.get_value(st.obs[0])          # library workspaces before capture
+    roll = GraphedRollout(env, pol, st, T)
+
+    def iteration():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        roll()
+        torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
+        with torch.no_grad():
+            nv = pol.get_value(st.obs[-1])
+        st.compute_returns(nv, True, 0.99, 0.95)
+        agent.update(st)
+        st.reset()
+        torch.cuda.synchronize()
+        return t_roll, time.perf_counter() - t0
+
+    iteration()                     # captures both graphs (and trains one step)
+    t_roll, t_all = iteration()
     return {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
-            "ppo_epoch": 1, "mini_batches": 50, "note": "policy forward + env.step + storage per step, then GAE + one PPO epoch"}
+            "ppo_epoch": 1, "mini_batches": 50,
+            "note": "policy forward + env.step + storage per step, then GAE + one PPO epoch; rollout and mini-batch step replayed from HIP graphs"}
 
 
 def main():

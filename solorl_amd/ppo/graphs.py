@@ -1,0 +1,186 @@
+"""HIP-graph capture of the two launch-bound loops of PPO training on a GPU (PyTorch's CUDAGraph API is
+hipGraph on ROCm).
+
+At 4096 envs the engine's step kernel takes ~0.2 ms, a policy forward ~10 small kernels and a PPO
+mini-batch step (gather, forward, losses, backward, clip, Adam) ~100 kernels of a few microseconds each:
+run eagerly, both loops are bound by launch latency and Python, not by the GPU.  Captured once and
+replayed, a whole T-step rollout is ONE graph launch and every mini-batch step one (two with a
+gradient all-reduce between them when world > 1).
+
+  GraphedRollout  act -> solorl_step (the C-ABI launch is captured like any other kernel: it is enqueued on
+                  torch's capturing stream and never synchronises) -> storage.append, T times
+  GraphedPPO      PPO.update with identical arithmetic (agents/ppo/ppo.py:34-89); mini-batch indices are
+                  read on the device from a permutation buffer at a device-side offset, so a replay needs
+                  no host-side argument
+
+Both fall back to nothing: they are only constructed for CUDA devices; train() uses them unless
+--no-hip-graphs is given."""
+import torch
+import torch.nn as nn
+
+from . import dist as D
+from .ppo import PPO
+
+
+def _side_stream_warmup(fn, iters=3):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(iters):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+
+
+class GraphedRollout:
+    """One graph = num_steps x (policy.act, env.step, storage.append [, episode-stat samples])."""
+
+    def __init__(self, envs, actor_critic, storage, num_steps, stats=None, stat_every=8):
+        self.envs, self.ac, self.storage, self.T, self.stats = envs, actor_critic, storage, num_steps, stats
+        self.stat_every = stat_every
+        self.graph = None
+        self._samples = []
+
+    def _body(self, record):
+        st = self.storage
+        assert st.step == 0, "graphed rollouts start at storage step 0"
+        for step in range(self.T):
+            with torch.no_grad():
+                value, action, logp = self.ac.act(st.obs[step])
+            obs, reward, done, info = self.envs.step_inplace(action.contiguous())
+            if record is not None and step % self.stat_every == self.stat_every - 1:
+                record.append((done.bool(), {k: v.clone() for k, v in info.items()}))
+            st.append(obs, action, logp, value, reward.unsqueeze(-1), (1.0 - done.float()).unsqueeze(-1))
+
+    def _capturable(self):
+        # contact-count sorting (N >= 8192 or SOLORL_SORT) ping-pongs two state buffers on the host side of
+        # solorl_step: a captured sequence is only self-consistent over an even number of steps
+        import os
+        sort = self.envs.nenvs >= 8192
+        if os.environ.get("SOLORL_SORT") is not None:
+            sort = os.environ["SOLORL_SORT"] != "0"
+        return not sort or self.T % 2 == 0
+
+    def __call__(self):
+        if not self._capturable():
+            from .train import rollout
+            return rollout(self.envs, self.ac, self.storage, self.T, self.stats)
+        if self.graph is None:
+            # no warm-up replay of the body: the env must not be stepped twice.  Everything the body allocates
+            # is allocated inside the capture (private pool); cuBLAS/hipBLASLt workspaces were created by the
+            # eager policy calls that precede the first rollout (train(): reset + get_value warm-up).
+            g = torch.cuda.CUDAGraph()
+            rec = [] if self.stats is not None else None
+            with torch.cuda.graph(g):
+                self._body(rec)
+            self.graph, self._samples = g, rec or []
+        self.graph.replay()
+        if self.stats is not None:
+            self.stats._pending = list(self._samples)      # static graph outputs, valid until the next replay
+
+
+class GraphedPPO(PPO):
+    """PPO with the mini-batch step captured.  Adam runs in capturable mode with the learning rate held in a
+    device tensor (update_linear_schedule fills it), otherwise the arithmetic is PPO.update's."""
+
+    def __init__(self, actor_critic, clip_param, ppo_epoch, mini_batch_size, value_loss_coef, entropy_coef, lr=None,
+                 l2_coef=0.0, max_grad_norm=None, use_clipped_value_loss=True):
+        super().__init__(actor_critic, clip_param, ppo_epoch, mini_batch_size, value_loss_coef, entropy_coef, lr=lr,
+                         l2_coef=l2_coef, max_grad_norm=max_grad_norm, use_clipped_value_loss=use_clipped_value_loss)
+        dev = next(actor_critic.parameters()).device
+        self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=torch.tensor(float(lr), device=dev),
+                                          weight_decay=l2_coef, capturable=True)
+        self._built_for = None
+
+    # ---- capture
+    def _build(self, storage):
+        dev = storage.device
+        n, m = storage.num_samples, self.mini_batch_size
+        flat = lambda x: x.reshape(n, *x.shape[2:])
+        self._src = (flat(storage.obs[:-1]), flat(storage.actions), flat(storage.value_preds[:-1]), flat(storage.returns[:-1]),
+                     flat(storage.action_log_probs))
+        assert all(s.data_ptr() == b.data_ptr() for s, b in zip(self._src, (storage.obs, storage.actions, storage.value_preds,
+                                                                            storage.returns, storage.action_log_probs)))
+        self._adv = torch.zeros(n, 1, device=dev)
+        self._perm = torch.zeros(n, dtype=torch.long, device=dev)
+        self._off = torch.zeros((), dtype=torch.long, device=dev)
+        self._ar = torch.arange(m, device=dev)
+        self._stats = torch.zeros(3, device=dev)
+        clip = self.clip_param
+
+        def fwd_bwd():
+            idx = self._perm.index_select(0, self._ar + self._off)
+            self._off += m
+            obs_b, act_b, vpred_b, ret_b, old_lp_b = (s.index_select(0, idx) for s in self._src)
+            adv_b = self._adv.index_select(0, idx)
+            values, logp, entropy = self.actor_critic.evaluate_actions(obs_b, act_b)
+            ratio = torch.exp(logp - old_lp_b)
+            action_loss = -torch.min(ratio * adv_b, torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * adv_b).mean()
+            if self.use_clipped_value_loss:
+                v_clipped = vpred_b + (values - vpred_b).clamp(-clip, clip)
+                value_loss = 0.5 * torch.max((values - ret_b).pow(2), (v_clipped - ret_b).pow(2)).mean()
+            else:
+                value_loss = 0.5 * (ret_b - values).pow(2).mean()
+            self.bucket.zero()
+            (value_loss * self.value_loss_coef + action_loss - entropy * self.entropy_coef).backward()
+            self._stats += torch.stack([value_loss.detach(), action_loss.detach(), entropy.detach()])
+
+        def opt_step():
+            if self.max_grad_norm is not None:
+                nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+
+        # warm-up on a side stream (allocator, autograd and optimizer state), then put everything back
+        params = [p for p in self.actor_critic.parameters()]
+        saved = [p.detach().clone() for p in params]
+        self._perm.copy_(torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(0)))   # (own generator: the
+                                                                                   # global RNG stream stays the eager path's)
+        def warm():
+            self._off.zero_()
+            fwd_bwd()
+            opt_step()
+        _side_stream_warmup(warm)
+        with torch.no_grad():
+            for p, s in zip(params, saved):
+                p.copy_(s)
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        self._stats.zero_(); self._off.zero_()
+        self._split = D.world() > 1
+        pool = torch.cuda.graph_pool_handle()
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1, pool=pool):
+            fwd_bwd()
+            if not self._split:
+                opt_step()
+        if self._split:                       # the RCCL all-reduce of the flat bucket runs between two graphs
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g2, pool=pool):
+                opt_step()
+        with torch.no_grad():                 # capture does not execute, but be explicit about the state we start from
+            self._stats.zero_(); self._off.zero_()
+        self._built_for = (id(storage), n, m)
+
+    def update(self, storage):
+        if not storage.rewards.is_cuda:
+            return super().update(storage)
+        if self._built_for != (id(storage), storage.num_samples, self.mini_batch_size):
+            self._build(storage)
+        n, m = storage.num_samples, self.mini_batch_size
+        adv = storage.returns[:-1] - storage.value_preds[:-1]
+        mean, std = D.global_mean_std(adv, unbiased=True)
+        self._adv.copy_(((adv - mean) / (std + 1e-5)).reshape(n, 1))
+        self._stats.zero_()
+        n_updates = 0
+        for _ in range(self.ppo_epoch):
+            self._perm.copy_(torch.randperm(n, device=storage.device))
+            self._off.zero_()
+            for _s in range(0, n - m + 1, m):
+                self._g1.replay()
+                if self._split:
+                    self.bucket.all_reduce_mean()
+                    self._g2.replay()
+                n_updates += 1
+        v, a, e = (self._stats / max(n_updates, 1)).tolist()
+        return v, a, e

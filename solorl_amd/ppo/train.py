@@ -20,6 +20,7 @@ import torch
 from . import dist as D
 from .policy import Policy
 from .ppo import PPO
+from .graphs import GraphedPPO, GraphedRollout
 from .storage import RolloutStorage
 
 
@@ -27,7 +28,10 @@ def update_linear_schedule(optimizer, epoch, total_num_epochs, initial_lr):
     """agents/utils.py:14-18: lr decays linearly to zero."""
     lr = initial_lr - (initial_lr * (epoch / float(total_num_epochs)))
     for g in optimizer.param_groups:
-        g["lr"] = lr
+        if torch.is_tensor(g["lr"]):      # capturable Adam (GraphedPPO): the graph reads the device tensor
+            g["lr"].fill_(lr)
+        else:
+            g["lr"] = lr
 
 
 class EpisodeStats:
@@ -83,19 +87,29 @@ def train(args, config, env_constructor=None, writer=None):
     base = torch.load(args.base_checkpoint) if getattr(args, "base_checkpoint", None) else None
     actor_critic = Policy(envs.observation_space.shape, envs.action_space, base, {"hidden_size": args.hidden_size}).to(device)
     D.broadcast_parameters(actor_critic)
-    agent = PPO(actor_critic, args.clip_param, args.ppo_epoch, args.mini_batch_size, args.value_loss_coef,
-                args.entropy_coef, lr=args.lr, l2_coef=args.l2_coef, max_grad_norm=args.max_grad_norm)
+    use_graphs = bool(args.cuda) and not getattr(args, "no_hip_graphs", False)
+    agent = (GraphedPPO if use_graphs else PPO)(actor_critic, args.clip_param, args.ppo_epoch, args.mini_batch_size,
+                                                 args.value_loss_coef, args.entropy_coef, lr=args.lr, l2_coef=args.l2_coef,
+                                                 max_grad_norm=args.max_grad_norm)
     storage = RolloutStorage(args.num_steps, N, envs.observation_space.shape, action_dim, device)
     storage.obs[0].copy_(envs.reset())
     torch.manual_seed(args.seed + 1000 * rank)        # but different action noise per rank
     stats = EpisodeStats()
+    if use_graphs:
+        with torch.no_grad():
+            actor_critic.act(storage.obs[0]); actor_critic.get_value(storage.obs[0])    # library workspaces before capture
+        torch.manual_seed(args.seed + 1000 * rank)
+        graphed_rollout = GraphedRollout(envs, actor_critic, storage, args.num_steps, stats)
     start = time.time()
     num_updates = int(args.num_env_steps) // args.num_steps // (N * world)
     history = []
     for j in range(num_updates):
         if args.use_linear_lr_decay:
             update_linear_schedule(agent.optimizer, j, num_updates, args.lr)
-        rollout(envs, actor_critic, storage, args.num_steps, stats)
+        if use_graphs:
+            graphed_rollout()
+        else:
+            rollout(envs, actor_critic, storage, args.num_steps, stats)
         with torch.no_grad():
             next_value = actor_critic.get_value(storage.obs[-1])
         storage.compute_returns(next_value, args.use_gae, args.gamma, args.tau)

@@ -18,7 +18,7 @@ def test_ppo_train_loop_runs_and_learns_something(gpu_device, tmp_path):
         num_agents=1024, hidden_size=64, cuda=True, gamma=0.99, tau=0.95, clip_param=0.1, ppo_epoch=2, mini_batch_size=4096,
         lr=2.5e-4, l2_coef=0.0, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5, use_linear_lr_decay=True,
         use_gae=True, num_env_steps=1024 * 32 * 3, seed=1, curriculum_schedule=0, log_interval=1, logdir=str(tmp_path),
-        base_checkpoint=None, save_interval=1, num_steps=32)
+        base_checkpoint=None, save_interval=1, num_steps=32)      # HIP-graph rollout + update (default on CUDA)
     pol, hist = train(args, config)
     assert len(hist) == 3 and all(h["fps"] > 0 for h in hist)
     assert all(torch.isfinite(p).all() for p in pol.parameters())
@@ -36,3 +36,33 @@ def test_ppo_train_loop_runs_and_learns_something(gpu_device, tmp_path):
     import numpy as np
     z = np.load(dump)
     assert z["q"].shape[1] == 12 and z["pos"].shape[1] == 3 and len(z["reward"]) == len(z["q"])
+
+
+def test_hip_graph_update_matches_eager(gpu_device):
+    """GraphedPPO (mini-batch step replayed from a HIP graph, capturable Adam) == PPO.update on the same
+    storage, permutations and initial weights."""
+    import copy
+    from solorl_amd.ppo import Policy, PPO, RolloutStorage
+    from solorl_amd.ppo.graphs import GraphedPPO
+    from solorl_amd.vec_env import Box
+    import numpy as np
+    dev = torch.device("cuda:0")
+    T, N, O, A = 16, 64, 76, 12
+    torch.manual_seed(0)
+    st = RolloutStorage(T, N, (O,), A, dev)
+    st.obs.normal_(); st.actions.normal_(); st.rewards.normal_(); st.value_preds.normal_(); st.action_log_probs.normal_().mul_(0.1).sub_(10)
+    st.masks.copy_((torch.rand_like(st.masks) > 0.05).float())
+    st.compute_returns(torch.randn(N, 1, device=dev), True, 0.99, 0.95)
+    pol_a = Policy((O,), Box(-np.ones(A), np.ones(A)), None, {"hidden_size": 64}).to(dev)
+    pol_b = copy.deepcopy(pol_a)
+    eager = PPO(pol_a, 0.1, 2, 256, 0.5, 0.01, lr=1e-3, max_grad_norm=0.5)
+    graph = GraphedPPO(pol_b, 0.1, 2, 256, 0.5, 0.01, lr=1e-3, max_grad_norm=0.5)
+    for it in range(2):                 # second round replays the graph captured in the first
+        torch.manual_seed(5 + it); la = eager.update(st)
+        torch.manual_seed(5 + it); lb = graph.update(st)
+        assert np.allclose(la, lb, rtol=1e-4, atol=1e-5), (la, lb)
+        # Adam's first steps move every weight by ~lr * sign(grad): elements whose gradient is rounding noise may
+        # differ by O(lr) between two correct implementations, so compare the parameter vectors in norm
+        va = torch.cat([p.detach().flatten() for p in pol_a.parameters()])
+        vb = torch.cat([p.detach().flatten() for p in pol_b.parameters()])
+        assert ((va - vb).norm() / va.norm()).item() < 1e-3 and (va - vb).abs().max().item() < 5e-3

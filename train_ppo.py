@@ -15,6 +15,7 @@ def get_ppo_args(argv=None):
     p.add_argument("--num-agents", type=int, default=32)          # envs PER GPU
     p.add_argument("--hidden-size", type=int, default=64)
     p.add_argument("--no-cuda", action="store_true", default=False)
+    p.add_argument("--no-hip-graphs", action="store_true", default=False, help="run rollout and update eagerly instead of replaying HIP graphs")
     p.add_argument("--env-name", type=str, default="base")
     p.add_argument("--gamma", type=float, default=0.99)
     p.add_argument("--tau", type=float, default=0.95)
