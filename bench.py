@@ -155,8 +155,12 @@ def main():
     k_avg = sum(kms) / len(kms)      # one step = sort + gather + step_kernel launches; the step kernel is >95 % of it
 
     ppo = None
-    if args.ppo_steps > 0:           # BASELINE config 3: the full PPO loop (rollout + GAE + clipped update) on the same engine
-        ppo = ppo_leg(env, dev, world, args.ppo_steps)
+    if args.ppo_steps > 0 and world == 1:   # (auxiliary leg, single GPU only: the scaling runs measure the headline metric)
+        # BASELINE config 3: the full PPO loop (rollout + GAE + clipped update) on the same engine
+        try:
+            ppo = ppo_leg(env, dev, world, args.ppo_steps)
+        except Exception as ex:      # the auxiliary leg must never take the headline measurement down with it
+            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0:
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
