@@ -1,4 +1,5 @@
 """Short end-to-end PPO run on the HIP engine (BASELINE config 3 shape at reduced length)."""
+import os
 import types
 
 import pytest
@@ -66,3 +67,51 @@ def test_hip_graph_update_matches_eager(gpu_device):
         va = torch.cat([p.detach().flatten() for p in pol_a.parameters()])
         vb = torch.cat([p.detach().flatten() for p in pol_b.parameters()])
         assert ((va - vb).norm() / va.norm()).item() < 1e-3 and (va - vb).abs().max().item() < 5e-3
+
+
+def _graph_worker(rank, world, port, q):
+    import numpy as np
+    import torch.distributed as dist
+    from solorl_amd.ppo import Policy, PPO, RolloutStorage
+    from solorl_amd.ppo.graphs import GraphedPPO
+    from solorl_amd.vec_env import Box
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors through the host: fine for a test
+    dev = torch.device("cuda:0")
+    T, N, O, A = 8, 32, 76, 12
+    g = torch.Generator(device=dev).manual_seed(100 + rank)            # every rank holds a different shard
+    st = RolloutStorage(T, N, (O,), A, dev)
+    for k in ("obs", "actions", "rewards", "value_preds"):
+        getattr(st, k).copy_(torch.randn(getattr(st, k).shape, device=dev, generator=g))
+    st.action_log_probs.copy_(torch.randn(st.action_log_probs.shape, device=dev, generator=g) * 0.1 - 10)
+    st.compute_returns(torch.randn(N, 1, device=dev, generator=g), True, 0.99, 0.95)
+    out = []
+    for cls in (PPO, GraphedPPO):
+        torch.manual_seed(3)
+        pol = Policy((O,), Box(-np.ones(A), np.ones(A)), None, {"hidden_size": 64}).to(dev)
+        agent = cls(pol, 0.1, 2, 64, 0.5, 0.01, lr=1e-3, max_grad_norm=0.5)
+        torch.manual_seed(9 + rank)
+        losses = agent.update(st)
+        v = torch.cat([p.detach().flatten() for p in pol.parameters()])
+        other = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(other, v)
+        assert torch.equal(other[0], other[1])                      # replicas stay identical
+        out.append((losses, v.cpu()))
+    (le, ve), (lg, vg) = out
+    ok = bool(np.allclose(le, lg, rtol=1e-4, atol=1e-5)) and ((ve - vg).norm() / ve.norm()).item() < 1e-3
+    q.put((rank, ok, le, lg))
+    dist.destroy_process_group()
+
+
+def test_hip_graph_update_world_size_2(gpu_device):
+    """world > 1: gradient all-reduce between the two graphs of a mini-batch step (two ranks sharing the one GPU)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(r[1] for r in res), res
