@@ -379,7 +379,7 @@ SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
 // ---------------------------------------------------------------- phase 2 (x4): one leg
 // FK + ABA passes 1-2, leg response (G, qdd0), parked limit and contact rows of this leg
 template <typename T, int ROBOT, int L, typename LDS, typename CH>
-SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -507,7 +507,7 @@ SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nst
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
       const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
       const T pen = C.dist[p] + pp.slop;
-      const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
+      const T lam0 = pp.warm * lam_prev[(unsigned)p * nstride];
       static_for<3>([&](auto dc) {
         constexpr int d = decltype(dc)::value;   // 0: normal (z), 1: friction x, 2: friction y
         V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
@@ -553,7 +553,7 @@ template <typename T> SD LegSign<T> leg_sign(int L) {
     else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
     else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds, int L) {
+SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -680,7 +680,7 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t 
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
       const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
       const T pen = C.dist[p] + pp.slop;
-      const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
+      const T lam0 = pp.warm * lam_prev[(unsigned)p * nstride];
       const T fric = SEL4(T, lsg, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
                           RB::MD.prims[18 + i].friction);
       static_for<3>([&](auto dc) {
@@ -708,7 +708,7 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t 
 // base_solve: parks the base primitives' rows, inverts the base articulated inertia, computes the
 // unconstrained velocities u* = u + dt*udot (C.ub, C.qds) and returns Lam and the padded leg rates.
 template <typename T, int ROBOT, typename LDS, bool TEAMQ = false, typename QOUT>
-SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS& lds,
+SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS& lds,
                    Sym6<T>& Lam, QOUT& qsl) {   // QOUT: T[4][3] padded leg rates, or (TEAMQ) SV<T> receiving a0
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -724,7 +724,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
         const int cidx = __popc(mask & ((1 << p) - 1));
         const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
         const V3<T> P = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
-        const T lam0 = pp.warm * lam_prev[(size_t)p * nstride];
+        const T lam0 = pp.warm * lam_prev[(unsigned)p * nstride];
         const T Z[3] = {T(0), T(0), T(0)};
         static_for<3>([&](auto dc) {
           constexpr int d = decltype(dc)::value;
@@ -787,7 +787,7 @@ SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const S
 }
 
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_base(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+SNI void phase_base(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   constexpr int LN = LDS::LANES;
   Sym6<T> Lam; T qsl[4][3];
@@ -916,7 +916,7 @@ SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
 // ---------------------------------------------------------------- phase 5: apply + integrate
 // delta-velocities (clamp K5), impulse cache, semi-implicit Euler (K1)
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_integrate(CH ch, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS lds) {
+SNI void phase_integrate(CH ch, const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -928,7 +928,7 @@ SNI void phase_integrate(CH ch, const PhysParams<T>& pp, T* lam_prev, size_t nst
     if constexpr (p < 12) {
       if ((mask >> p) & 1) l = lds.A(nlt + __popc(mask & ((1 << p) - 1)), LDS::A_LAM);
     } else l = C.lam_n[p - 12];
-    lam_prev[(size_t)p * nstride] = l;
+    lam_prev[(unsigned)p * nstride] = l;
   });
   const SV<T> w = C.w, ub = C.ub;
   PhysState<T, RB::NQ> st = C.ps;
@@ -1014,7 +1014,7 @@ template <typename T, typename LDS> struct TeamRows {
 // leader: base solve, then publish what the other lanes need (bc: Lam 36, u*_base 6, padded leg rates 12, -a0 6... see TeamRows)
 // TEAMQ = true: the leg rates u*_leg (C.qds, bc[42..]) are left to phase_legrates_team (one joint per lane).
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, size_t nstride, const LDS lds) {
+SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
@@ -1309,7 +1309,7 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
 // apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.
 // Reads the sweep's results straight from the team arrays (accumulators in hdr / y, impulses in lam).
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS lds, int t, bool valid,
+SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS lds, int t, bool valid,
                               bool lead) {
   using RB = Robot<ROBOT>;
   using TRW = TeamRows<T, LDS>;
@@ -1321,7 +1321,7 @@ SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, size_
   const T* lam = TRW::lam(lds.lane);
   for (int p = t; p < NPRIM; p += 16) {       // warm-start cache: normal impulse of primitive p (its rank among the contacts)
     const T l = ((mask >> p) & 1) ? lam[(TRW::NPOS0 + __popc(mask & ((1 << p) - 1))) * 4] : T(0);
-    lam_prev[(size_t)p * nstride] = l;
+    lam_prev[(unsigned)p * nstride] = l;
   }
   const T* hdr = lds.hdr();
   const SV<T> w{{hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]}, {hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]}};
@@ -1368,7 +1368,7 @@ template <typename T, int ROBOT, typename LDS> struct TeamCtx {
 
 // the leader's context C lives in LDS (see CtxLds); `C` is only dereferenced by leader lanes
 template <typename T, int ROBOT, typename LDS>
-SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds, int t, bool lead, bool valid) {
+SD int substep_team(const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS& lds, int t, bool lead, bool valid) {
   constexpr int LN = LDS::LANES;
   using TRW = TeamRows<T, LDS>;
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
@@ -1404,7 +1404,7 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, size_t nstride, const 
 // C.ps / C.tau: state and the joint torques applied during this sub-step.  lam_prev: per-primitive
 // warm-start impulses (global memory, stride = nstride).  Returns the contact bit mask.
 template <typename T, int ROBOT, typename LDS>
-SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, size_t nstride, const LDS& lds) {
+SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS& lds) {
   using CH = CtxPriv<T, ROBOT>;
   const CH ch{&C};
   phase_detect<T, ROBOT, CH>(ch, pp);

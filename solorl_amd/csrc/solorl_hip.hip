@@ -36,6 +36,8 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SOLORL_ERR_HIP, std::string(#x ": ") + hipGetErrorString(e_)); } while (0)
 
 constexpr int DMAX = SOLORL_STATE_MAX_OBS;   // 42
+using idx_t = unsigned;   // device-side element indices: 32-bit (solorl_create checks NF*N and O*N < 2^31); 64-bit index
+                          // arithmetic made every state access ~10 VALU instructions
 
 // field-major state layout (offsets in units of N elements)
 struct Layout {
@@ -101,8 +103,8 @@ template <typename T, int NQ> struct Env {
 };
 
 template <typename T, int NQ>
-SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, size_t N, size_t e) {
-  auto F = [&](int f) { return sf[(size_t)f * N + e]; };
+SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, idx_t N, idx_t e) {
+  auto F = [&](int f) { return sf[(idx_t)f * N + e]; };
   E.ps.pos = mk(F(L.pos), F(L.pos + 1), F(L.pos + 2));
   E.ps.qx = F(L.quat); E.ps.qy = F(L.quat + 1); E.ps.qz = F(L.quat + 2); E.ps.qw = F(L.quat + 3);
   E.ps.v = mk(F(L.v), F(L.v + 1), F(L.v + 2)); E.ps.w = mk(F(L.w), F(L.w + 1), F(L.w + 2));
@@ -113,11 +115,11 @@ SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, siz
 #pragma unroll
   for (int k = 0; k < 5; k++) E.dr[k] = F(L.dr + k);
   E.xyprev[0] = F(L.xyprev); E.xyprev[1] = F(L.xyprev + 1);
-  E.timestep = si[(size_t)I_TIMESTEP * N + e]; E.mask = si[(size_t)I_MASK * N + e]; E.rng = si[(size_t)I_RNG * N + e];
+  E.timestep = si[(idx_t)I_TIMESTEP * N + e]; E.mask = si[(idx_t)I_MASK * N + e]; E.rng = si[(idx_t)I_RNG * N + e];
 }
 template <typename T, int NQ>
-SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, size_t N, size_t e) {
-  auto F = [&](int f, T v) { sf[(size_t)f * N + e] = v; };
+SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, idx_t N, idx_t e) {
+  auto F = [&](int f, T v) { sf[(idx_t)f * N + e] = v; };
   F(L.pos, E.ps.pos.x); F(L.pos + 1, E.ps.pos.y); F(L.pos + 2, E.ps.pos.z);
   F(L.quat, E.ps.qx); F(L.quat + 1, E.ps.qy); F(L.quat + 2, E.ps.qz); F(L.quat + 3, E.ps.qw);
   F(L.v, E.ps.v.x); F(L.v + 1, E.ps.v.y); F(L.v + 2, E.ps.v.z);
@@ -129,7 +131,7 @@ SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, size_t N
 #pragma unroll
   for (int k = 0; k < 5; k++) F(L.dr + k, E.dr[k]);
   F(L.xyprev, E.xyprev[0]); F(L.xyprev + 1, E.xyprev[1]);
-  si[(size_t)I_TIMESTEP * N + e] = E.timestep; si[(size_t)I_MASK * N + e] = E.mask; si[(size_t)I_RNG * N + e] = E.rng;
+  si[(idx_t)I_TIMESTEP * N + e] = E.timestep; si[(idx_t)I_MASK * N + e] = E.mask; si[(idx_t)I_RNG * N + e] = E.rng;
 }
 
 // SoloBase.get_current_state (solo.py:198-222): D values, compile-time indices
@@ -145,7 +147,7 @@ SD void current_state(const Env<T, Robot<ROBOT>::NQ>& E, int task, T (&cs)[DMAX]
   cs[4] = E.ps.v.x; cs[5] = E.ps.v.y; cs[6] = E.ps.v.z;
   cs[7] = E.ps.w.x; cs[8] = E.ps.w.y; cs[9] = E.ps.w.z;
 #pragma unroll
-  for (int j = 0; j < NQ; j++) { cs[10 + j] = E.ps.q[j] / T(10); cs[10 + NQ + j] = E.ps.qd[j] / T(100); }
+  for (int j = 0; j < NQ; j++) { cs[10 + j] = E.ps.q[j] * T(0.1); cs[10 + NQ + j] = E.ps.qd[j] * T(0.01); }   // (/10, /100: solo.py:208-209)
 #pragma unroll
   for (int f = 0; f < 4; f++) cs[10 + 2 * NQ + f] = ((E.mask >> (13 + 2 * f)) & 1) ? T(1) : T(0);
   if (task == SOLORL_TASK_POINTGOAL) {
@@ -166,7 +168,7 @@ SD void sample_goal(Env<T, NQ>& E, const EnvParams& P, long long gid) {   // sol
 
 // SoloBaseEnv.reset (baseEnv.py:70-82) in O(1): load the pre-simulated post-settle state.
 template <typename T, int ROBOT>
-SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L, size_t N, size_t e, size_t env, const T* snf,
+SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L, idx_t N, idx_t e, idx_t env, const T* snf,
                             const int* sni, int M, const EnvParams& P) {
   constexpr int NQ = Robot<ROBOT>::NQ;
   const long long gid = P.id0 + (long long)env;
@@ -180,19 +182,19 @@ SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L,
   unsigned r[4];
   philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)rng++, 2u, r);
   const int k = (int)(r[0] % (unsigned)P.nsettle);
-  load_env(S, snf, sni, L, (size_t)M, (size_t)k);
+  load_env(S, snf, sni, L, (idx_t)M, (idx_t)k);
   E = S;
   E.rng = rng; E.timestep = 0;
   E.goal[0] = g0; E.goal[1] = g1; E.goals = T(0); E.egoals = T(0);
 #pragma unroll
   for (int q = 0; q < 5; q++) E.dr[q] = T(0);
-  for (int p = 0; p < NPRIM; p++) sf[(size_t)(L.lam + p) * N + e] = snf[(size_t)(L.lam + p) * M + k];
+  for (int p = 0; p < NPRIM; p++) sf[(idx_t)(L.lam + p) * N + e] = snf[(idx_t)(L.lam + p) * M + k];
   for (int h = 0; h < L.H; h++)
-    for (int d = 0; d < L.D; d++) sf[(size_t)(L.hist + h * DMAX + d) * N + e] = snf[(size_t)(L.hist + h * DMAX + d) * M + k];
+    for (int d = 0; d < L.D; d++) sf[(idx_t)(L.hist + h * DMAX + d) * N + e] = snf[(idx_t)(L.hist + h * DMAX + d) * M + k];
   if (P.task == SOLORL_TASK_POINTGOAL) {
     for (int h = 0; h < L.H; h++) {
-      sf[(size_t)(L.hist + h * DMAX + L.D - 2) * N + e] = g0 * T(0.5);
-      sf[(size_t)(L.hist + h * DMAX + L.D - 1) * N + e] = g1 * T(0.5);
+      sf[(idx_t)(L.hist + h * DMAX + L.D - 2) * N + e] = g0 * T(0.5);
+      sf[(idx_t)(L.hist + h * DMAX + L.D - 1) * N + e] = g1 * T(0.5);
     }
     T dx = E.ps.pos.x - g0, dy = E.ps.pos.y - g1, px = E.xyprev[0] - g0, py = E.xyprev[1] - g1;
     E.pot = sqrt(dx * dx + dy * dy);
@@ -201,18 +203,36 @@ SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L,
 }
 
 template <typename T, int ROBOT>
-SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& L, size_t N, size_t e, size_t env, int task, float* obs) {
+SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& L, idx_t N, idx_t e, idx_t env, int task, float* obs) {
   T cs[DMAX];
+#ifdef SOLO_PHASE_TIMING
+  long long wt_ = clock64();
+#define WOBS_TICK(i) do { const long long n_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&solo::solo_phase_cycles[i], (unsigned long long)(n_ - wt_)); wt_ = clock64(); } while (0)
+#else
+#define WOBS_TICK(i) do {} while (0)
+#endif
   current_state<T, ROBOT>(E, task, cs);
+  WOBS_TICK(13);
   const int O = L.D * (1 + L.H);
-  float* o = obs + env * (size_t)O;
-  // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older]
+  float* o = obs + env * (idx_t)O;
+  // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older].  All history loads are issued
+  // before the first store: obs and the state may alias as far as the compiler knows, and a load -> wait ->
+  // store chain per element cost 38 dependent memory round trips (13 us of a 210 us step).
+  T hv[2][DMAX];
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) hv[h][d] = (h < L.H && d < L.D) ? sf[(idx_t)(L.hist + h * DMAX + d) * N + e] : T(0);
+  WOBS_TICK(14);
 #pragma unroll
   for (int d = 0; d < DMAX; d++)
     if (d < L.D) {
       o[d] = (float)cs[d];
-      for (int h = 0; h < L.H; h++) o[(h + 1) * L.D + d] = (float)(cs[d] - sf[(size_t)(L.hist + h * DMAX + d) * N + e]);
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        if (h < L.H) o[(h + 1) * L.D + d] = (float)(cs[d] - hv[h][d]);
     }
+  WOBS_TICK(15);
 }
 
 // ---------------------------------------------------------------- the hot kernel
@@ -241,18 +261,16 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   // 128-B line; workgroup ids go round-robin over the 8 XCDs (each with its own L2), hence give every XCD one
   // CONTIGUOUS eighth of the env range instead of every eighth workgroup (grid is a multiple of 8).
   const unsigned blk = TEAM ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  size_t e = (size_t)blk * EPB + col;
-  const bool valid = e < (size_t)N;
+  idx_t e = (idx_t)blk * EPB + col;
+  const bool valid = e < (idx_t)N;
   if (!TEAM && !valid) return;
-  if (!valid) e = (size_t)N - 1;           // team mode keeps every lane alive for the wave-level exchanges
+  if (!valid) e = (idx_t)N - 1;           // team mode keeps every lane alive for the wave-level exchanges
   const bool lead = valid && t == 0;
   LDS lds; lds.lanes = EPB; lds.lane = col;
-  size_t env = 0;
+  idx_t env = 0;
   Env<T, NQ> E;
-  if (lead) {
-    env = (size_t)si[(size_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
-    load_env(E, sf, si, L, (size_t)N, e);
-  }
+  if (TEAM ? valid : true) env = (idx_t)si[(idx_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
+  if (lead) load_env(E, sf, si, L, (idx_t)N, e);
 
   // ---- A3 apply_action
   T tau[NQ], asq = T(0);
@@ -272,14 +290,43 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   }
 
   // ---- A4 simulator_step: history push (pre-step state), frame_skip sub-steps
-  if (lead && L.H > 0) {
-    T cs[DMAX];
+  // Team mode: the leader publishes the D state values through LDS (the `bc` block is free outside the sub-steps)
+  // and lane t moves elements t, t+16, t+32 -- 64-B coalesced segments, 3 instead of 38 load/store rounds -- and
+  // keeps what it wrote (hk0 = new newest = pre-step state, hk1 = old newest) for the observation at the end.
+  constexpr int HK = (DMAX + 15) / 16;
+  T hk0[HK], hk1[HK];
+#pragma unroll
+  for (int k = 0; k < HK; k++) { hk0[k] = T(0); hk1[k] = T(0); }
+  if constexpr (TEAM) {
+    T* stage = TeamRows<T, LDS>::bc(col);
+    if (lead && L.H > 0) {
+      T cs[DMAX];
+      current_state<T, ROBOT>(E, P.task, cs);
+#pragma unroll
+      for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
+    }
+    if (valid && L.H > 0) {
+#pragma unroll
+      for (int k = 0; k < HK; k++) {
+        const int d = t + 16 * k;
+        if (d < L.D) {
+          const T c = stage[d];
+          if (L.H == 2) { hk1[k] = sf[(idx_t)(L.hist + d) * N + e]; sf[(idx_t)(L.hist + DMAX + d) * N + e] = hk1[k]; }
+          sf[(idx_t)(L.hist + d) * N + e] = c;
+          hk0[k] = c;
+        }
+      }
+    }
+  } else if (L.H > 0) {
+    T cs[DMAX], h0[DMAX];
     current_state<T, ROBOT>(E, P.task, cs);
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) h0[d] = (L.H == 2 && d < L.D) ? sf[(idx_t)(L.hist + d) * N + e] : T(0);   // loads first (see write_obs)
 #pragma unroll
     for (int d = 0; d < DMAX; d++)
       if (d < L.D) {
-        if (L.H == 2) sf[(size_t)(L.hist + DMAX + d) * N + e] = sf[(size_t)(L.hist + d) * N + e];
-        sf[(size_t)(L.hist + d) * N + e] = cs[d];
+        if (L.H == 2) sf[(idx_t)(L.hist + DMAX + d) * N + e] = h0[d];
+        sf[(idx_t)(L.hist + d) * N + e] = cs[d];
       }
   }
   E.xyprev[0] = E.ps.pos.x; E.xyprev[1] = E.ps.pos.y;
@@ -297,7 +344,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #pragma unroll
         for (int j = 0; j < NQ; j++) ch.get().tau[j] = tau[j] * sc;
       }
-      const int m = substep_team<T, ROBOT>(pp, sf + (size_t)L.lam * N + e, (size_t)N, lds, t, lead, valid);
+      const int m = substep_team<T, ROBOT>(pp, sf + (idx_t)L.lam * N + e, (idx_t)N, lds, t, lead, valid);
       if (lead) E.mask = m;
     }
     if (lead) E.ps = ch.get().ps;
@@ -312,18 +359,20 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
 #pragma unroll
       for (int j = 0; j < NQ; j++) C.tau[j] = tau[j] * sc;
-      E.mask = substep<T, ROBOT>(C, pp, sf + (size_t)L.lam * N + e, (size_t)N, lds);
+      E.mask = substep<T, ROBOT>(C, pp, sf + (idx_t)L.lam * N + e, (idx_t)N, lds);
     }
     E.ps = C.ps;
   }
-  if (!lead) return;
+  int team_obs = 0;          // team mode: 1 = the lanes write the observation together (the env did not reset)
+  if (lead) {
   if (P.task == SOLORL_TASK_POINTGOAL && mode == MODE_STEP) {
     T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
     T np = sqrt(dx * dx + dy * dy);
     E.prog = -(np - E.pot); E.pot = np;
     if (np < T(0.5)) { E.goals += T(1); sample_goal(E, P, P.id0 + (long long)env); }
   }
-  if (mode == MODE_SETTLE) { store_env(E, sf, si, L, (size_t)N, e); return; }
+  if (mode == MODE_SETTLE) store_env(E, sf, si, L, (idx_t)N, e);
+  else {
   E.timestep += 1;
 
   // ---- A7 reward (baseEnv.py:91-157)
@@ -378,19 +427,50 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[9], (unsigned long long)(clock64() - kstart_));
 #endif
-  if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, env, snf, sni, M, P);
+  if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (idx_t)N, e, env, snf, sni, M, P);
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[10], (unsigned long long)(clock64() - kstart_));
 #endif
-  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, env, P.task, out.obs);
+  if (TEAM && !done) {        // publish the new state values; all 16 lanes write the observation below
+    T cs[DMAX];
+    current_state<T, ROBOT>(E, P.task, cs);
+    if constexpr (TEAM) {
+      T* stage = TeamRows<T, LDS>::bc(col);
+#pragma unroll
+      for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
+    }
+    team_obs = 1;
+  } else write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, env, P.task, out.obs);   // (a reset rewrote the history: leader only)
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[11], (unsigned long long)(clock64() - kstart_));
 #endif
-  store_env(E, sf, si, L, (size_t)N, e);
+  store_env(E, sf, si, L, (idx_t)N, e);
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[12], (unsigned long long)(clock64() - kstart_));
 #endif
+  }   // mode == MODE_STEP
+  }   // lead
+  if constexpr (TEAM) {
+    // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older], element d on lane d mod 16
+    team_obs = __shfl(team_obs, 0, 16);
+    if (valid && team_obs) {
+      const T* stage = TeamRows<T, LDS>::bc(col);
+      float* o = out.obs + env * (idx_t)(L.D * (1 + L.H));
+#pragma unroll
+      for (int k = 0; k < HK; k++) {
+        const int d = t + 16 * k;
+        if (d < L.D) {
+          const T c = stage[d];
+          o[d] = (float)c;
+          if (L.H >= 1) o[L.D + d] = (float)(c - hk0[k]);
+          if (L.H == 2) o[2 * L.D + d] = (float)(c - hk1[k]);
+        }
+      }
+    }
+  }
 }
+
+
 
 template <typename T, int ROBOT>
 __global__ void __launch_bounds__(64)
@@ -408,44 +488,44 @@ step_kernel_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__
 
 template <typename T, int ROBOT>
 __global__ void reset_kernel(T* sf, int* si, const T* snf, const int* sni, int M, Layout L, int N, EnvParams P, float* obs) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)N) return;
+  const idx_t e = (idx_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (idx_t)N) return;
   Env<T, Robot<ROBOT>::NQ> E;
-  load_env(E, sf, si, L, (size_t)N, e);
-  const size_t env = (size_t)si[(size_t)I_ENVID * N + e];
-  reset_from_snapshot<T, ROBOT>(E, sf, L, (size_t)N, e, env, snf, sni, M, P);
-  if (obs) write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, env, P.task, obs);
-  store_env(E, sf, si, L, (size_t)N, e);
-  si[(size_t)I_NEEDRESET * N + e] = 0;
+  load_env(E, sf, si, L, (idx_t)N, e);
+  const idx_t env = (idx_t)si[(idx_t)I_ENVID * N + e];
+  reset_from_snapshot<T, ROBOT>(E, sf, L, (idx_t)N, e, env, snf, sni, M, P);
+  if (obs) write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, env, P.task, obs);
+  store_env(E, sf, si, L, (idx_t)N, e);
+  si[(idx_t)I_NEEDRESET * N + e] = 0;
 }
 
 template <typename T, int ROBOT>
 __global__ void obs_kernel(const T* sf, const int* si, Layout L, int N, int task, float* obs) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)N) return;
+  const idx_t e = (idx_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (idx_t)N) return;
   Env<T, Robot<ROBOT>::NQ> E;
-  load_env(E, sf, si, L, (size_t)N, e);
-  write_obs<T, ROBOT>(E, sf, L, (size_t)N, e, (size_t)si[(size_t)I_ENVID * N + e], task, obs);
+  load_env(E, sf, si, L, (idx_t)N, e);
+  write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, (idx_t)si[(idx_t)I_ENVID * N + e], task, obs);
 }
 
 // initial pose of SoloBase.robot_specific_reset (solo.py:291-296) for every env of a buffer
 template <typename T>
 __global__ void init_pose_kernel(T* sf, int* si, Layout L, int N) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)N) return;
-  for (int f = 0; f < L.NF; f++) sf[(size_t)f * N + e] = T(0);
-  sf[(size_t)(L.pos + 2) * N + e] = T(0.35);
-  sf[(size_t)(L.quat + 3) * N + e] = T(1);
-  for (int k = 0; k < NI; k++) si[(size_t)k * N + e] = 0;
-  si[(size_t)I_NEEDRESET * N + e] = 1;
-  si[(size_t)I_ENVID * N + e] = (int)e;
+  const idx_t e = (idx_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (idx_t)N) return;
+  for (int f = 0; f < L.NF; f++) sf[(idx_t)f * N + e] = T(0);
+  sf[(idx_t)(L.pos + 2) * N + e] = T(0.35);
+  sf[(idx_t)(L.quat + 3) * N + e] = T(1);
+  for (int k = 0; k < NI; k++) si[(idx_t)k * N + e] = 0;
+  si[(idx_t)I_NEEDRESET * N + e] = 1;
+  si[(idx_t)I_ENVID * N + e] = (int)e;
 }
 
 template <typename T>
 __global__ void copy_env_kernel(const T* sf, const int* si, int N, int src, T* df, int* di, int M, int dst, int NF) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < NF) df[(size_t)f * M + dst] = sf[(size_t)f * N + src];
-  if (f < NI) di[(size_t)f * M + dst] = si[(size_t)f * N + src];
+  if (f < NF) df[(idx_t)f * M + dst] = sf[(idx_t)f * N + src];
+  if (f < NI) di[(idx_t)f * M + dst] = si[(idx_t)f * N + src];
 }
 
 // ---- contact-count sorting (divergence control for the PGS sweep)
@@ -460,7 +540,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
   const int t = threadIdx.x, nt = blockDim.x;
   const int chunk = (N + nt - 1) / nt, lo = t * chunk, hi = lo + chunk < N ? lo + chunk : N;
   int c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = lo; i < hi; i++) { int k = __popc(si[(size_t)I_MASK * N + i]); k = k > 8 ? 8 : k; c[k]++; }
+  for (int i = lo; i < hi; i++) { int k = __popc(si[(idx_t)I_MASK * N + i]); k = k > 8 ? 8 : k; c[k]++; }
 #pragma unroll
   for (int k = 0; k < 9; k++) cnt[t][k] = c[k];
   __syncthreads();
@@ -476,7 +556,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
 #pragma unroll
   for (int k = 0; k < 9; k++) off[k] = base[k] + cnt[t][k];
   for (int i = lo; i < hi; i++) {
-    int k = __popc(si[(size_t)I_MASK * N + i]); k = k > 8 ? 8 : k;
+    int k = __popc(si[(idx_t)I_MASK * N + i]); k = k > 8 ? 8 : k;
     int d = 0;
 #pragma unroll
     for (int q = 0; q < 9; q++) if (q == k) d = off[q]++;
@@ -491,8 +571,8 @@ __global__ void gather_state_kernel(const T* __restrict__ sf, const int* __restr
   if (j >= N) return;
   const int src = perm[j];
   const int f = blockIdx.y;
-  if (f < NF) df[(size_t)f * N + j] = sf[(size_t)f * N + src];
-  else di[(size_t)(f - NF) * N + j] = si[(size_t)(f - NF) * N + src];
+  if (f < NF) df[(idx_t)f * N + j] = sf[(idx_t)f * N + src];
+  else di[(idx_t)(f - NF) * N + j] = si[(idx_t)(f - NF) * N + src];
 }
 
 // ---- fused GAE / discounted returns (agents/ppo/storage.py:35-55): one thread per env walks the rollout
@@ -721,6 +801,9 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     h->epw = epw;
   }
   auto cleanup = [&](int code) { solorl_destroy(h); return code; };
+  if ((unsigned long long)h->L.NF * (unsigned long long)num_envs >= (1ull << 31) ||
+      (unsigned long long)(h->L.D * (1 + h->L.H)) * (unsigned long long)num_envs >= (1ull << 31))
+    return cleanup(fail(SOLORL_ERR_INVALID, "num_envs too large for 32-bit element indices"));
   if (hipMalloc(&h->sf, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state"));
   if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
   if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));

@@ -29,7 +29,7 @@ for t in range(K): env.step_inplace(a[t % 16])
 torch.cuda.synchronize()
 L.solorl_debug_phase_cycles(buf, 0)
 nw = (N + 3) // 4
-names = ["detect", "legs", "base_lead", "finish", "(unused)", "pgs", "readback+integrate", "kernel prologue (to first substep)", "kernel to end of substeps", "kernel to after reward/termination/outputs", "kernel to after auto-reset", "kernel to after write_obs", "kernel to after store_env"]
+names = ["detect", "legs", "base_lead", "finish", "(unused)", "pgs", "readback+integrate", "kernel prologue (to first substep)", "kernel to end of substeps", "kernel to after reward/termination/outputs", "kernel to after auto-reset", "kernel to after write_obs", "kernel to after store_env", "write_obs: current_state (euler)", "write_obs: history loads issued", "write_obs: stores issued"]
 tot = 0
 for i, n in enumerate(names):
     per = buf[i] / K / nw
