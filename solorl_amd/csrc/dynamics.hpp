@@ -34,6 +34,16 @@ constexpr int NPRIM = 20;
 constexpr double LIMIT_WINDOW = 0.5;
 constexpr double DISC_EPS2 = 1e-12;
 
+// dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
+#if defined(SOLO_PHASE_TIMING) && !defined(SOLO_HOST_SHIM)
+__device__ unsigned long long solo_phase_cycles[48];
+#define SOLO_TICK(i) do { const long long now_ = clock64(); if (threadIdx.x == 0) atomicAdd(&solo_phase_cycles[i], (unsigned long long)(now_ - tick_)); tick_ = clock64(); } while (0)
+#define SOLO_TICK_INIT long long tick_ = clock64()
+#else
+#define SOLO_TICK(i) do {} while (0)
+#define SOLO_TICK_INIT do {} while (0)
+#endif
+
 template <int N, typename F, int... I>
 SD void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F> SD void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
@@ -1350,16 +1360,6 @@ SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, unsig
     C.ps.qx = nx * inv; C.ps.qy = ny * inv; C.ps.qz = nz * inv; C.ps.qw = nq * inv;
   }
 }
-
-// dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
-#ifdef SOLO_PHASE_TIMING
-__device__ unsigned long long solo_phase_cycles[16];
-#define SOLO_TICK(i) do { const long long now_ = clock64(); if (threadIdx.x == 0) atomicAdd(&solo_phase_cycles[i], (unsigned long long)(now_ - tick_)); tick_ = clock64(); } while (0)
-#define SOLO_TICK_INIT long long tick_ = clock64()
-#else
-#define SOLO_TICK(i) do {} while (0)
-#define SOLO_TICK_INIT do {} while (0)
-#endif
 
 template <typename T, int ROBOT, typename LDS> struct TeamCtx {
   using type = CtxLds<T, ROBOT, TeamRows<T, LDS>::off_ctx>;

@@ -729,9 +729,9 @@ extern "C" {
 const char* solorl_last_error(void) { return g_err.c_str(); }
 
 #ifdef SOLO_PHASE_TIMING
-int solorl_debug_phase_cycles(unsigned long long* out16, int reset) {   // dev builds only (tools/dev/phase_timing.py)
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(solo::solo_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_phase_cycles), z, sizeof(z)) != hipSuccess) return -3; }
+int solorl_debug_phase_cycles(unsigned long long* out16, int reset) {   // (48 values)   // dev builds only (tools/dev/phase_timing.py)
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(solo::solo_phase_cycles), 48 * sizeof(unsigned long long)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_phase_cycles), z, sizeof(z)) != hipSuccess) return -3; }
   return 0;
 }
 int solorl_debug_pgs_cycles(unsigned long long* out20, int reset) {

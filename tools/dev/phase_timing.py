@@ -20,7 +20,7 @@ a = torch.rand(16, N, 12, device="cuda:0") * 2 - 1
 for t in range(100): env.step_inplace(a[t % 16])
 torch.cuda.synchronize()
 L = _native.lib()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 48)()
 L.solorl_debug_phase_cycles(buf, 1)
 pg = (C.c_ulonglong * 20)()
 L.solorl_debug_pgs_cycles(pg, 1)
