@@ -273,6 +273,7 @@ template <typename T, int ROBOT> struct SubCtx {
   LegResp<T, NJ> LR[4];
   SV<T> ub; T qds[NQ];
   SV<T> w; T y[4][3]; T lam_n[8];
+  T lamp[NPRIM];                   // team mode: warm-start impulse cache, held in LDS across the sub-steps of a step
 };
 
 // Context handles: the phases take the context through a handle so that its address space survives the
@@ -311,7 +312,7 @@ SD void park_row(const LDS& lds, int slot, SV<T> f0, const T (&JL)[3], const T (
 // start-of-step pose (K1, K6'): support points, contact mask, MAX_CONTACTS cap, row counts
 // SINCOS_DONE: C.sn / C.cs were already filled (team mode: one joint per lane, substep_team)
 template <typename T, int ROBOT, typename CH, bool SINCOS_DONE = false>
-SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
+SNI void phase_detect(CH ch, const PhysParams<T> pp) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NQ = RB::NQ;
@@ -389,7 +390,7 @@ SNI void phase_detect(CH ch, const PhysParams<T>& pp) {
 // ---------------------------------------------------------------- phase 2 (x4): one leg
 // FK + ABA passes 1-2, leg response (G, qdd0), parked limit and contact rows of this leg
 template <typename T, int ROBOT, int L, typename LDS, typename CH>
-SNI void phase_leg(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds) {
+SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -563,7 +564,7 @@ template <typename T> SD LegSign<T> leg_sign(int L) {
     else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
     else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {
+SNI void phase_leg_rt(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -690,7 +691,7 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigne
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
       const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
       const T pen = C.dist[p] + pp.slop;
-      const T lam0 = pp.warm * lam_prev[(unsigned)p * nstride];
+      const T lam0 = pp.warm * C.lamp[p];
       const T fric = SEL4(T, lsg, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
                           RB::MD.prims[18 + i].friction);
       static_for<3>([&](auto dc) {
@@ -718,7 +719,7 @@ SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigne
 // base_solve: parks the base primitives' rows, inverts the base articulated inertia, computes the
 // unconstrained velocities u* = u + dt*udot (C.ub, C.qds) and returns Lam and the padded leg rates.
 template <typename T, int ROBOT, typename LDS, bool TEAMQ = false, typename QOUT>
-SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS& lds,
+SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS& lds,
                    Sym6<T>& Lam, QOUT& qsl) {   // QOUT: T[4][3] padded leg rates, or (TEAMQ) SV<T> receiving a0
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -734,7 +735,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
         const int cidx = __popc(mask & ((1 << p) - 1));
         const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
         const V3<T> P = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
-        const T lam0 = pp.warm * lam_prev[(unsigned)p * nstride];
+        const T lam0 = pp.warm * (TEAMQ ? C.lamp[p] : lam_prev[(unsigned)p * nstride]);
         const T Z[3] = {T(0), T(0), T(0)};
         static_for<3>([&](auto dc) {
           constexpr int d = decltype(dc)::value;
@@ -778,7 +779,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, const T* lam_pr
 // finish one parked row: W = Lam f0, 1/diagonal, right-hand side (speculative / ERP, or friction)
 template <typename T>
 SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const SV<T>& ub, T q0, T q1, T q2,
-                   const PhysParams<T>& pp, SV<T>& W, T& rhs, T& dinv) {
+                   const PhysParams<T> pp, SV<T>& W, T& rhs, T& dinv) {
   const int dir = (meta >> 8) & 3;
   const SV<T> f0{{c[0], c[1], c[2]}, {c[3], c[4], c[5]}};
   const V3<T> P = mk(c[9], c[10], c[11]);
@@ -797,7 +798,7 @@ SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const S
 }
 
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_base(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds) {
+SNI void phase_base(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   constexpr int LN = LDS::LANES;
   Sym6<T> Lam; T qsl[4][3];
@@ -926,7 +927,7 @@ SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
 // ---------------------------------------------------------------- phase 5: apply + integrate
 // delta-velocities (clamp K5), impulse cache, semi-implicit Euler (K1)
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_integrate(CH ch, const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS lds) {
+SNI void phase_integrate(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -1021,10 +1022,117 @@ template <typename T, typename LDS> struct TeamRows {
   }
 };
 
+// OR over the 16 lanes of a team (every lane ends with the full value)
+SD int team_or16(int x) {
+  x |= __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+  x |= __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+  x |= __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);    // row_half_mirror
+  x |= __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true);    // row_mirror
+  return x;
+}
+
+// rare path of the collision phase: more than MAX_CONTACTS primitives touch -- keep the deepest (ties: lower id)
+template <typename T, int ROBOT, typename CH>
+SNI int cap_contacts(CH ch, int mask) {
+  const SubCtx<T, ROBOT>& C = ch.get();
+  T dist[NPRIM];
+#pragma unroll
+  for (int p = 0; p < NPRIM; p++) dist[p] = C.dist[p];
+  int keep = 0;
+  for (int p = 0; p < NPRIM; p++) {
+    int rank = 0;
+    for (int q = 0; q < NPRIM; q++)
+      if (q != p) rank += ((mask >> q) & 1) && (dist[q] < dist[p] || (dist[q] == dist[p] && q < p));
+    if (((mask >> p) & 1) && rank < MAX_CONTACTS) keep |= 1 << p;
+  }
+  return keep;
+}
+
+// Collision detection, team mode (replaces phase_detect): the four legs' support points on lanes 0..3, the
+// twelve base points on lanes 4..15, joint-limit tests one joint per lane; masks are OR-reduced over the team.
+// The leader then records the counts and starts the articulated-inertia accumulation with the base link.
+template <typename T, int ROBOT, typename LDS, typename CH>
+SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, bool valid, bool lead) {
+  using RB = Robot<ROBOT>;
+  constexpr int NJ = RB::NJ, NQ = RB::NQ, ST = NJ + 1;
+  SubCtx<T, ROBOT>& C = ch.get();
+  const PhysState<T, NQ>& st = C.ps;
+  const M3<T> R0 = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
+  const T pz = st.pos.z;
+  int bits = 0, lbits = 0;
+  if (valid && t < 4) {
+    const int L = t;
+    const LegSign<T> lsg = leg_sign<T>(L);
+#define LEGC(k, f) SEL4(T, lsg, RB::MD.links[1 + 0 * ST + (k)].f, RB::MD.links[1 + 1 * ST + (k)].f, \
+                        RB::MD.links[1 + 2 * ST + (k)].f, RB::MD.links[1 + 3 * ST + (k)].f)
+#define PRIMC(i, f) SEL4(T, lsg, RB::MD.prims[12 + (i)].f, RB::MD.prims[14 + (i)].f, RB::MD.prims[16 + (i)].f, RB::MD.prims[18 + (i)].f)
+    M3<T> Rp = R0;
+    V3<T> op = mk(T(0), T(0), T(0));
+    V3<T> kneeP = op, footP = op;
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int AX = RB::MD.links[1 + k].axis[0] != 0.0 ? 0 : 1;   // same for all legs
+      const V3<T> o = op + mul(Rp, mk(LEGC(k, jorigin[0]), LEGC(k, jorigin[1]), LEGC(k, jorigin[2])));
+      const M3<T> R = rot_axis<AX>(Rp, C.cs[L * NJ + k], C.sn[L * NJ + k]);
+      if constexpr (k == NJ - 2)   // knee disc sits on the upper leg
+        kneeP = disc_point(R, o + mul(R, mk(PRIMC(0, center[0]), PRIMC(0, center[1]), PRIMC(0, center[2]))), PRIMC(0, radius));
+      if constexpr (k == NJ - 1)   // foot: fixed child of the last link, primitive centred on its origin
+        footP = disc_point(R, o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2]))), PRIMC(1, radius));
+      Rp = R; op = o;
+    });
+    C.kneeP[L] = kneeP; C.footP[L] = footP;
+    const T dk = pz + kneeP.z, df = pz + footP.z;
+    C.dist[12 + 2 * L] = dk; C.dist[13 + 2 * L] = df;
+    if (dk < PRIMC(0, margin)) bits |= 1 << (12 + 2 * L);
+    if (df < PRIMC(1, margin)) bits |= 1 << (13 + 2 * L);
+#undef PRIMC
+#undef LEGC
+  } else if (valid) {
+    const int p = t - 4;     // base point p: centre and margin picked from the twelve compile-time values
+    T cx = T(0), cy = T(0), cz = T(0), mg = T(0);
+    static_for<12>([&](auto pc) {
+      constexpr int q = decltype(pc)::value;
+      constexpr solorl_prim_data PR = RB::MD.prims[q];
+      static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
+      if (p == q) { cx = T(PR.center[0]); cy = T(PR.center[1]); cz = T(PR.center[2]); mg = T(PR.margin); }
+    });
+    const T d = pz + R0.c0.z * cx + R0.c1.z * cy + R0.c2.z * cz;
+    C.dist[p] = d;
+    if (d < mg) bits |= 1 << p;
+  }
+  if (valid && t < NQ) {    // joint limits: bit 2j = lower window, 2j+1 = upper window (same order as the row slots)
+    const T q = st.q[t];
+    if (q + pp.qlim < T(LIMIT_WINDOW)) lbits |= 1 << (2 * t);
+    if (pp.qlim - q < T(LIMIT_WINDOW)) lbits |= 1 << (2 * t + 1);
+  }
+  int mask = team_or16(bits);
+  lbits = team_or16(lbits);
+  if (__popc(mask) > MAX_CONTACTS) {
+    if (lead) C.mask = cap_contacts<T, ROBOT, CH>(ch, mask);
+    mask = C.mask;                                     // (LDS: written by the leader just above, same wave)
+  }
+  if (!lead) return;
+  C.R0 = R0;
+  const int nl = __popc(lbits);
+  C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
+#pragma unroll
+  for (int L = 0; L < 4; L++) {
+    const int run = __popc(lbits & ((1 << (2 * NJ * L)) - 1));
+    C.limoff[L] = run > MAX_LIMITS ? MAX_LIMITS : run;
+  }
+  // base link terms start the articulated-inertia accumulation
+  constexpr solorl_link_data B = RB::MD.links[0];
+  static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
+  RBI<T> Ib; SV<T> pb;
+  link_terms(R0, mk(T(0), T(0), T(0)), T(B.mass), T(B.inertia_box[0]), T(B.inertia_box[1]), T(B.inertia_box[2]),
+             SV<T>{st.w, st.v}, pp.damping, Ib, pb);
+  C.Ibase = to_abi(Ib); C.pbase = pb;
+}
+
 // leader: base solve, then publish what the other lanes need (bc: Lam 36, u*_base 6, padded leg rates 12, -a0 6... see TeamRows)
 // TEAMQ = true: the leg rates u*_leg (C.qds, bc[42..]) are left to phase_legrates_team (one joint per lane).
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds) {
+SNI void phase_base_lead(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
@@ -1049,7 +1157,7 @@ SNI void phase_base_lead(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsi
 
 // unconstrained leg rates u*_leg = qd + dt (qdd0 - G.a0), clamped: joint t on lane t (padded copy for the rows)
 template <typename T, int ROBOT, typename LDS, typename CH>
-SD void phase_legrates_team(CH ch, const PhysParams<T>& pp, const LDS lds, int t) {
+SD void phase_legrates_team(CH ch, const PhysParams<T> pp, const LDS lds, int t) {
   using RB = Robot<ROBOT>;
   using TRW = TeamRows<T, LDS>;
   constexpr int NJ = RB::NJ;
@@ -1080,7 +1188,7 @@ template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt
 
 // all 16 lanes: lane t finishes rows t, t+16 and writes them as team records (layout: TeamRows)
 template <typename T, int ROBOT, typename LDS>
-SNI void phase_finish_team(const PhysParams<T>& pp, const LDS lds, int t) {
+SNI void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
   const int col = lds.lane;
   int nlt, nc, ncmax, anylim;
@@ -1319,7 +1427,7 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
 // apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.
 // Reads the sweep's results straight from the team arrays (accumulators in hdr / y, impulses in lam).
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS lds, int t, bool valid,
+SNI void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS lds, int t, bool valid,
                               bool lead) {
   using RB = Robot<ROBOT>;
   using TRW = TeamRows<T, LDS>;
@@ -1331,7 +1439,7 @@ SNI void phase_integrate_team(CH ch, const PhysParams<T>& pp, T* lam_prev, unsig
   const T* lam = TRW::lam(lds.lane);
   for (int p = t; p < NPRIM; p += 16) {       // warm-start cache: normal impulse of primitive p (its rank among the contacts)
     const T l = ((mask >> p) & 1) ? lam[(TRW::NPOS0 + __popc(mask & ((1 << p) - 1))) * 4] : T(0);
-    lam_prev[(unsigned)p * nstride] = l;
+    C.lamp[p] = l;
   }
   const T* hdr = lds.hdr();
   const SV<T> w{{hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]}, {hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]}};
@@ -1368,7 +1476,7 @@ template <typename T, int ROBOT, typename LDS> struct TeamCtx {
 
 // the leader's context C lives in LDS (see CtxLds); `C` is only dereferenced by leader lanes
 template <typename T, int ROBOT, typename LDS>
-SD int substep_team(const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS& lds, int t, bool lead, bool valid) {
+SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS& lds, int t, bool lead, bool valid) {
   constexpr int LN = LDS::LANES;
   using TRW = TeamRows<T, LDS>;
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
@@ -1380,9 +1488,15 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, unsigned nstride, cons
     sincos_t(C.ps.q[t], sn, cs);
     C.sn[t] = sn; C.cs[t] = cs;
   }
-  if (lead) phase_detect<T, ROBOT, CH, true>(ch, pp);
+  phase_front_team<T, ROBOT, LDS, CH>(ch, pp, lds, t, valid, lead);
+#ifdef SOLO_DUP_FRONT      // dev: run an idempotent phase twice -- the launch-time delta is that phase's true cost
+  phase_front_team<T, ROBOT, LDS, CH>(ch, pp, lds, t, valid, lead);
+#endif
   SOLO_TICK(0);
   if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);   // four legs on four lanes
+#ifdef SOLO_DUP_LEGS
+  if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);
+#endif
   SOLO_TICK(1);
   if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   else if (!valid && t == 0) {   // idle team: no rows
@@ -1391,6 +1505,9 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, unsigned nstride, cons
   if (valid) phase_legrates_team<T, ROBOT, LDS, CH>(ch, pp, lds, t);
   SOLO_TICK(2);
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
+#ifdef SOLO_DUP_FINISH
+  phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
+#endif
   SOLO_TICK(3);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
   SOLO_TICK(5);
@@ -1404,7 +1521,7 @@ SD int substep_team(const PhysParams<T>& pp, T* lam_prev, unsigned nstride, cons
 // C.ps / C.tau: state and the joint torques applied during this sub-step.  lam_prev: per-primitive
 // warm-start impulses (global memory, stride = nstride).  Returns the contact bit mask.
 template <typename T, int ROBOT, typename LDS>
-SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T>& pp, T* lam_prev, unsigned nstride, const LDS& lds) {
+SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS& lds) {
   using CH = CtxPriv<T, ROBOT>;
   const CH ch{&C};
   phase_detect<T, ROBOT, CH>(ch, pp);

@@ -337,6 +337,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
 #endif
     if (lead) ch.get().ps = E.ps;
+    // warm-start impulse cache: HBM -> LDS once per step (a global load/store per sub-step left a memory round
+    // trip exposed at every phase boundary: the non-inlined calls wait for all outstanding VMEM)
+    if (valid) for (int p = t; p < NPRIM; p += 16) ch.get().lamp[p] = sf[(idx_t)(L.lam + p) * N + e];
 #pragma unroll 1
     for (int ss = 0; ss < P.frame_skip; ss++) {
       const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
@@ -348,6 +351,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       if (lead) E.mask = m;
     }
     if (lead) E.ps = ch.get().ps;
+    if (valid) for (int p = t; p < NPRIM; p += 16) sf[(idx_t)(L.lam + p) * N + e] = ch.get().lamp[p];
 #ifdef SOLO_PHASE_TIMING
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[8], (unsigned long long)(clock64() - kstart_));
 #endif
