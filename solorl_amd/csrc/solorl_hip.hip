@@ -812,7 +812,8 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
   if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
   if (hipMalloc(&h->sni, sizeof(int) * NI * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
-  h->sort = num_envs >= 8192;   // measured: below one full round of waves sorting only adds its own 20 us
+  h->sort = false;   // measured with the team-mode sweep (tools/dev/bench_sort.sh): the sort + gather launches cost more than the
+                     // padding they save at every batch size (65 536 envs: 29.5 M vs 23.8 M env-steps/s); SOLORL_SORT=1 enables it
   if (const char* ev = getenv("SOLORL_SORT")) h->sort = atoi(ev) != 0 && num_envs >= 2;
   if (h->sort) {
     if (hipMalloc(&h->sf2, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state2"));

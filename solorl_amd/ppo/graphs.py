@@ -52,12 +52,10 @@ class GraphedRollout:
             st.append(obs, action, logp, value, reward.unsqueeze(-1), (1.0 - done.float()).unsqueeze(-1))
 
     def _capturable(self):
-        # contact-count sorting (N >= 8192 or SOLORL_SORT) ping-pongs two state buffers on the host side of
+        # contact-count sorting (opt-in, SOLORL_SORT=1) ping-pongs two state buffers on the host side of
         # solorl_step: a captured sequence is only self-consistent over an even number of steps
         import os
-        sort = self.envs.nenvs >= 8192
-        if os.environ.get("SOLORL_SORT") is not None:
-            sort = os.environ["SOLORL_SORT"] != "0"
+        sort = os.environ.get("SOLORL_SORT", "0") != "0"
         return not sort or self.T % 2 == 0
 
     def __call__(self):
