@@ -564,7 +564,8 @@ template <typename T> SD LegSign<T> leg_sign(int L) {
     else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
     else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_leg_rt(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {
+SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {   // (by reference:
+                                                                     // ten more live argument registers made this phase spill 101 VGPRs)
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -972,23 +973,11 @@ SNI void phase_integrate(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned ns
 }
 
 #ifndef SOLO_HOST_SHIM
-// ---------------------------------------------------------------- team mode (small batches)
-// 16 lanes (one DPP row) per env, 4 envs per wavefront.  The team leader (lane 0 of the row) runs the
-// phases above; the PGS sweep -- the critical path -- is shared by the whole row: the 18 accumulator
-// components [w(6), y_leg0..3 (12)] live one (two for lanes 0,1) per lane, a row update is
-//   partial = J[c]*acc[c]  ->  4-step DPP butterfly sum  ->  replicated clamp  ->  acc[c] += B[c]*delta
-// i.e. ~30 instructions per row instead of ~85 for a lone lane doing all 18 multiply-adds.
-template <typename T> SD T team_sum16(T x) {
-  if constexpr (sizeof(T) == 4) {
-    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
-  } else {
-    x += __shfl_xor(x, 1, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 8, 16);
-  }
-  return x;
-}
+// ---------------------------------------------------------------- team mode (default)
+// 16 lanes (one DPP row) per env, 4 envs per wavefront.  Per sub-step (substep_team): sin/cos, collision
+// points, leg rates and integration run one joint / primitive per lane, the four legs on four lanes, the
+// base solve on the team leader (lane 0 of the row); rows are finished by all 16 lanes and swept by
+// pgs_team_variant, where each 8-lane half holds the 18 accumulator components [w(6), y_leg0..3 (12)].
 
 // Team-sweep row storage (after the RowLds<T,4> region).  Rows sit at STATIC positions, two per slot:
 //   slot 0        positions 0,1           the (<= 2) joint-limit rows

@@ -81,3 +81,26 @@ def test_reference_yaml_configs_load():
         config_from_dict(dict(episode_length=10, control="vpd"))
     with pytest.raises(ValueError):
         config_from_dict(dict(episode_length=10, task="fly"))
+
+
+def test_team_mode_phases_do_not_spill_or_use_flat(lib):
+    """Static check of the built code object: the fp32 Solo12/Solo8 team-mode phases keep their state in VGPRs
+    and LDS (no scratch traffic, no FLAT access to the context); the sweeps of up to 6 contacts -- 99.6 % of the
+    launches of the headline workload -- do not spill either."""
+    from solorl_amd import devcode
+    st = devcode.function_stats(build.LIB)
+    hot = [n for n in st if re.search(r"phase_(front|leg_rt|base_lead|finish|integrate)_?(team)?I?f", n) and "IfLi" in n and "CtxPriv" not in n
+           and "RowLdsIfLi64" not in n]
+    assert len(hot) >= 10, sorted(st)[:5]          # 5 phases x 2 robots
+    for n in hot:
+        assert st[n]["scratch"] <= 4, (n, st[n])   # (a couple of callee-saved registers around the rare cap_contacts call)
+        assert st[n]["flat"] <= 9, (n, st[n])      # phase_leg_rt reads 9 PhysParams fields through its reference argument
+        assert st[n]["global"] == 0, (n, st[n])
+    sweeps = {n: s for n, s in st.items() if "pgs_team_variantIfNS" in n}
+    assert len(sweeps) == 17
+    for n, s in sweeps.items():
+        m = re.search(r"Li(\d)ELi(\d)ELi(\d)EEE", n)
+        lim, nn, nf = (int(x) for x in m.groups())
+        assert s["flat"] == 0 and s["global"] == 0
+        if nf <= 5 or (nf == 6 and lim == 0):
+            assert s["scratch"] == 0, (n, s)
