@@ -752,7 +752,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, const T* lam_pre
     park_row(lds, 0, zero6<T>(), Z, Z, mk(T(0), T(0), T(0)), T(0), T(0), T(0), 0);
   }
   // base acceleration (gravity via the accelerating-frame trick), u* = u + dt*udot
-  Lam = spd_inverse(C.Ibase);
+  Lam = spd_inverse_block(C.Ibase);
   const SV<T> a0 = mul(Lam, C.pbase) * T(-1);
   if constexpr (TEAMQ) qsl = a0;
   else {
@@ -1118,6 +1118,23 @@ SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, b
   C.Ibase = to_abi(Ib); C.pbase = pb;
 }
 
+// base articulated inertia / bias = base link + the four legs' contributions (phase_leg_rt): the 21 + 6 values
+// are summed one (two) per lane straight in the LDS context
+template <typename T, int ROBOT, typename CH>
+SD void team_sum_base(CH ch, int t) {
+  SubCtx<T, ROBOT>& C = ch.get();
+  constexpr int NA = (int)(sizeof(ABI<T>) / sizeof(T)), NP = (int)(sizeof(SV<T>) / sizeof(T));
+  static_assert(NA == 21 && NP == 6, "ABI / SV are plain arrays of T");
+  T* ib = reinterpret_cast<T*>(&C.Ibase); T* pb = reinterpret_cast<T*>(&C.pbase);
+  const T* il = reinterpret_cast<const T*>(&C.Ileg[0]); const T* pl = reinterpret_cast<const T*>(&C.pleg[0]);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int i = t + 16 * k;
+    if (i < NA) ib[i] = ib[i] + ((il[i] + il[NA + i]) + (il[2 * NA + i] + il[3 * NA + i]));
+    else if (i < NA + NP) { const int j = i - NA; pb[j] = pb[j] + ((pl[j] + pl[NP + j]) + (pl[2 * NP + j] + pl[3 * NP + j])); }
+  }
+}
+
 // leader: base solve, then publish what the other lanes need (bc: Lam 36, u*_base 6, padded leg rates 12, -a0 6... see TeamRows)
 // TEAMQ = true: the leg rates u*_leg (C.qds, bc[42..]) are left to phase_legrates_team (one joint per lane).
 template <typename T, int ROBOT, typename LDS, typename CH>
@@ -1125,12 +1142,6 @@ SNI void phase_base_lead(CH ch, const PhysParams<T> pp, const T* lam_prev, unsig
   SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
-  {   // base articulated inertia / bias = base link + the four legs' contributions (phase_leg_rt)
-    ABI<T> Ib = C.Ibase; SV<T> pb = C.pbase;
-#pragma unroll
-    for (int L = 0; L < 4; L++) { add(Ib, C.Ileg[L]); pb = pb + C.pleg[L]; }
-    C.Ibase = Ib; C.pbase = pb;
-  }
   Sym6<T> Lam; SV<T> a0;
   base_solve<T, ROBOT, LDS, true>(C, pp, lam_prev, nstride, lds, Lam, a0);
   T* bc = TRW::bc(lds.lane);
@@ -1487,6 +1498,10 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);
 #endif
   SOLO_TICK(1);
+  if (valid) team_sum_base<T, ROBOT, CH>(ch, t);
+#ifdef SOLO_DUP_BASE       // dev timing (tools/dev/dup_phase.sh); idempotent now that the leg sum is a separate step
+  if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+#endif
   if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
