@@ -330,3 +330,27 @@ def test_lane_mode_sorting_and_team_mode_agree(gpu_device):
     for other in (team_sorted, lane):
         d = (team - other).abs()[:, :, 16:28]     # joint angles / 10 rad: the north-star quantity
         assert d.median().item() * 10 < 1e-5 and torch.quantile(d.flatten(), 0.9).item() * 10 < 1e-3
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 63, 65])
+def test_ragged_batch_sizes(gpu_device, n):
+    """Batch sizes that do not fill a team wavefront (4 envs) or a workgroup round (multiples of 8 workgroups):
+    idle teams must neither disturb their neighbours nor write anything."""
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    env, orc = make(c, n, seed=6)
+    og = env.reset().cpu().numpy().astype(np.float64); oo = orc.reset()
+    assert og.shape == oo.shape == (n, c.obs_dim)
+    assert obs_diff(og, oo, c.state_dim).max() < 2e-3
+    rng = np.random.default_rng(n)
+    guard = torch.full((n + 8, 12), 7.0, device="cuda:0")          # actions live in a larger buffer: nothing beyond n is read as an env
+    dq = []
+    for t in range(6):
+        a = (0.4 * rng.uniform(-1, 1, size=(n, 12))).astype(np.float32)
+        guard[:n] = torch.from_numpy(a).cuda()
+        for i in range(n):
+            orc.set_state(i, env.get_state(i))
+        o, r, d, _ = env.step(guard[:n])
+        orc.step(a.astype(np.float64))
+        assert o.shape == (n, c.obs_dim) and torch.isfinite(o).all()
+        dq += [np.abs(np.array(env.get_state(i).q) - np.array(orc.get_state(i).q)).max() for i in range(n)]
+    assert np.median(dq) < 1e-4 and np.max(dq) < 5e-2

@@ -1,0 +1,10 @@
+"""PPO-loop leg only (for rocprofv3 --kernel-trace --stats): rollout graph + update graphs, two iterations."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch, bench
+from solorl_amd.config import default_config, ROBOT_SOLO12, TASK_WALK
+from solorl_amd.vec_env import SoloVecEnv
+dev = torch.device("cuda:0")
+cfg = default_config(ROBOT_SOLO12, TASK_WALK); cfg.num_history_stack = 1
+env = SoloVecEnv(cfg, 4096, device=dev, seed=1); env.reset()
+print(bench.ppo_leg(env, dev, 1, 64))
