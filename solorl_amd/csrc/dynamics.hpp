@@ -727,7 +727,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, const T* lam_pre
   const T dt = pp.dt;
   const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
   const int nrows = nlt + 3 * nc;
-  if (mask & 0xFFF) {   // base contacts: f0 = F, no leg part
+  if (!TEAMQ && (mask & 0xFFF)) {   // base contacts: f0 = F, no leg part (team mode: parked by phase_front_team)
     const M3<T> R0 = C.R0;
     static_for<12>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
@@ -1049,6 +1049,7 @@ SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, b
   const M3<T> R0 = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
   const T pz = st.pos.z;
   int bits = 0, lbits = 0;
+  V3<T> bP = mk(T(0), T(0), T(0)); T bdist = T(0), bfric = T(0);      // base lanes: their point, distance, friction
   if (valid && t < 4) {
     const int L = t;
     const LegSign<T> lsg = leg_sign<T>(L);
@@ -1077,17 +1078,18 @@ SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, b
 #undef PRIMC
 #undef LEGC
   } else if (valid) {
-    const int p = t - 4;     // base point p: centre and margin picked from the twelve compile-time values
+    const int p = t - 4;     // base point p: centre, margin, friction picked from the twelve compile-time values
     T cx = T(0), cy = T(0), cz = T(0), mg = T(0);
     static_for<12>([&](auto pc) {
       constexpr int q = decltype(pc)::value;
       constexpr solorl_prim_data PR = RB::MD.prims[q];
       static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
-      if (p == q) { cx = T(PR.center[0]); cy = T(PR.center[1]); cz = T(PR.center[2]); mg = T(PR.margin); }
+      if (p == q) { cx = T(PR.center[0]); cy = T(PR.center[1]); cz = T(PR.center[2]); mg = T(PR.margin); bfric = T(PR.friction); }
     });
-    const T d = pz + R0.c0.z * cx + R0.c1.z * cy + R0.c2.z * cz;
-    C.dist[p] = d;
-    if (d < mg) bits |= 1 << p;
+    bP = mul(R0, mk(cx, cy, cz));
+    bdist = pz + bP.z;
+    C.dist[p] = bdist;
+    if (bdist < mg) bits |= 1 << p;
   }
   if (valid && t < NQ) {    // joint limits: bit 2j = lower window, 2j+1 = upper window (same order as the row slots)
     const T q = st.q[t];
@@ -1100,9 +1102,22 @@ SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, b
     if (lead) C.mask = cap_contacts<T, ROBOT, CH>(ch, mask);
     mask = C.mask;                                     // (LDS: written by the leader just above, same wave)
   }
+  const int nl = __popc(lbits);
+  if (valid && t >= 4 && ((mask >> (t - 4)) & 1)) {    // base contacts: every touching point parks its own three rows
+    const int p = t - 4, nlt = nl > MAX_LIMITS ? MAX_LIMITS : nl, nc = __popc(mask);
+    const int cidx = __popc(mask & ((1 << p) - 1));
+    const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
+    const T lam0 = pp.warm * C.lamp[p];
+    const T Z[3] = {T(0), T(0), T(0)};
+    static_for<3>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      const V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
+      park_row(lds, d == 0 ? sn_ : sf_ + (d - 1), SV<T>{cross(bP, u), u}, Z, Z, bP, bdist + pp.slop, d == 0 ? lam0 : T(0), bfric,
+               (d == 0 ? 0 : (sn_ | 128)) | (d << 8));
+    });
+  }
   if (!lead) return;
   C.R0 = R0;
-  const int nl = __popc(lbits);
   C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
 #pragma unroll
   for (int L = 0; L < 4; L++) {
