@@ -1231,17 +1231,24 @@ SNI void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
 #pragma unroll
     for (int j = 0; j < 6; j++) Lam.m[i][j] = bc[i * 6 + j];
   const SV<T> ub{{bc[36], bc[37], bc[38]}, {bc[39], bc[40], bc[41]}};
-  for (int r = t; r < nrows; r += 16) {
-    T c[ROW_CORE];
-    lds.load_core(r, c);
-    const int meta = (int)lds.A(r, LDS::A_META);
+  // rows t and t + 16 (the second only for >= 17 rows, i.e. the heaviest teams -- the ones that set the launch time):
+  // both rows' loads are issued before either row's stores so that their LDS latencies overlap instead of adding up
+  const int r1 = t + 16;
+  const bool two = r1 < nrows;
+  T c0[ROW_CORE], c1[ROW_CORE];
+  lds.load_core(t, c0);
+  const int meta0 = (int)lds.A(t, LDS::A_META);
+  const T mu0 = lds.A(t, LDS::A_MU);
+  int meta1 = 0; T mu1 = T(1);
+  if (two) { lds.load_core(r1, c1); meta1 = (int)lds.A(r1, LDS::A_META); mu1 = lds.A(r1, LDS::A_MU); }
+  auto emit = [&](int r, const T (&c)[ROW_CORE], int meta, T mu) {
     const int leg = (meta >> 5) & 3;
     const T* ql = bc + 42 + leg * 3;
     SV<T> W; T rhs, dinv;
     finish_row(c, meta, Lam, ub, ql[0], ql[1], ql[2], pp, W, rhs, dinv);
     const bool fr = r >= rfric;
     const int pos = TRW::pos_of(r, nlt, nc);
-    const T sB = fr ? lds.A(r, LDS::A_MU) : T(1);
+    const T sB = fr ? mu : T(1);
     const T sJ = dinv / sB;
     T* q = rec + pos * (4 * TRW::REC);
     T* sc = sca + pos * (4 * TRW::SCA);
@@ -1253,7 +1260,9 @@ SNI void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
     ql2[0] = c[6] * sJ; ql2[1] = c[15] * sB; ql2[2] = c[7] * sJ; ql2[3] = c[16] * sB; ql2[4] = c[8] * sJ; ql2[5] = c[17] * sB;
     sc[0] = rhs / sB;                   // finish_row's rhs already carries 1/diag
     lam[pos * 4] = c[13];               // warm-start impulse (0 for friction / limit rows)
-  }
+  };
+  emit(t, c0, meta0, mu0);
+  if (two) emit(r1, c1, meta1, mu1);
 }
 
 // exchange between the two 8-lane halves of a 16-lane team (values are uniform within a half)
