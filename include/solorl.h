@@ -14,6 +14,8 @@
  *   solorl_increment_curriculum <- agents/ppo/envs.py:125-127 (pointgoal: solo.py:332-334)
  *   solorl_compute_returns <- agents/ppo/storage.py:35-55 (OPBuffer.compute_returns: GAE / discounted returns;
  *                             400 sequential tiny torch ops per update in the reference)
+ *   solorl_ppo_loss        <- agents/ppo/ppo.py:52-74 (clipped surrogate + clipped value loss) with the Gaussian
+ *                             log-prob of agents/ppo/policy.py:51-58,171-173: ~60 elementwise torch kernels per mini-batch
  *   solorl_get_state / solorl_set_state : no reference counterpart (parity-test hooks)
  *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
  *
@@ -145,6 +147,17 @@ int solorl_compute_returns(const float* rewards /* [T*N] */, float* value_preds 
                            const float* masks /* [(T+1)*N] */, const float* next_value /* [N] */,
                            float* returns /* [(T+1)*N] */, int T, int N, int use_gae, float gamma,
                            float gae_lambda, int device_id, void* stream);
+
+/* Fused PPO mini-batch loss, forward + gradients w.r.t. the policy heads (device arrays, m samples, A action dims):
+ *   logp_i = sum_j -0.5 z_ij^2 - logstd_j - log sqrt(2 pi),  z = (action - mean) exp(-logstd);  ratio = exp(logp - old_logp)
+ *   action loss = -mean_i min(ratio adv, clamp(ratio, 1-clip, 1+clip) adv)                                  (ppo.py:54-59)
+ *   value  loss = 0.5 mean_i max((v - ret)^2, (vpred + clamp(v - vpred, +-clip) - ret)^2)  [clipped_value]  (ppo.py:61-68)
+ * Outputs: grad_mean [m*A] = d(action loss)/d mean, grad_values [m] = value_coef * d(value loss)/d v, and per-block
+ * partial sums partials[ceil(m/256)][3 + A] = (sum value loss, sum action loss, count, d(action loss)/d logstd[A]);
+ * the caller adds the blocks (deterministic) and the entropy term, which does not depend on the samples. */
+int solorl_ppo_loss(const float* mean, const float* logstd, const float* values, const float* action, const float* old_logp,
+                    const float* adv, const float* vpred, const float* ret, int m, int A, float clip, float value_coef,
+                    int clipped_value, float* grad_mean, float* grad_values, float* partials, int device_id, void* stream);
 
 const char* solorl_last_error(void);
 const char* solorl_version(void);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/solorl.h declares
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
            "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state",
-           "solorl_compute_returns", "solorl_last_error", "solorl_version")
+           "solorl_compute_returns", "solorl_ppo_loss", "solorl_last_error", "solorl_version")
 
 
 class SoloRLError(RuntimeError):
@@ -41,6 +41,8 @@ def lib():
         L.solorl_increment_curriculum.argtypes = [C.c_void_p, C.c_double]
         L.solorl_get_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(EnvState)]
         L.solorl_set_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(EnvState)]
+        L.solorl_ppo_loss.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p]
         L.solorl_compute_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                              C.c_float, C.c_float, C.c_int, C.c_void_p]
         for s in SYMBOLS:

@@ -610,6 +610,78 @@ __global__ void returns_kernel(const float* __restrict__ rew, float* __restrict_
   }
 }
 
+// ---- fused clipped-surrogate PPO loss (agents/ppo/ppo.py:52-74 + the diagonal-Gaussian log-prob / entropy of
+// agents/ppo/policy.py:51-58,171-173): forward AND the gradients w.r.t. the network heads in one pass over a
+// mini-batch.  One thread per sample; per-block partial sums (deterministic: reduced by the caller), layout
+//   part[block][0..2] = sum value-loss, sum action-loss, sample count;  part[block][3 .. 3+A) = d loss / d logstd.
+// Sub-gradient conventions are torch's: minimum/maximum split ties evenly, clamp passes the gradient on its
+// closed interval -- with both branches equal on a tie the result is the plain derivative.
+__global__ void __launch_bounds__(256)
+ppo_loss_kernel(const float* __restrict__ mean, const float* __restrict__ logstd, const float* __restrict__ values,
+                const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
+                const float* __restrict__ vpred, const float* __restrict__ ret, int m, int A, float clip, float value_coef,
+                int clipped_value, float* __restrict__ g_mean, float* __restrict__ g_values, float* __restrict__ part) {
+  extern __shared__ float red[];                  // [256][3 + A] would not fit for large A: reduce column by column
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = i < m;
+  const float inv_m = 1.0f / (float)m;
+  float vl = 0.f, al = 0.f, glp = 0.f;
+  float lp = 0.f;
+  if (on) {
+    for (int j = 0; j < A; j++) {
+      const float ls = logstd[j];
+      const float z = (action[(size_t)i * A + j] - mean[(size_t)i * A + j]) * __expf(-ls);
+      lp += -0.5f * z * z - ls - 0.91893853320467274178f;
+    }
+    const float ratio = __expf(lp - old_logp[i]);
+    const float a = adv[i];
+    const float s1 = ratio * a;
+    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    const float s2 = rc * a;
+    al = -fminf(s1, s2);
+    const float inside = (ratio >= 1.0f - clip && ratio <= 1.0f + clip) ? 1.0f : 0.0f;
+    // d min(s1, s2) / d logp:  s1 branch = a*ratio, s2 branch = a*ratio*inside
+    const float w = s1 < s2 ? 1.0f : (s1 > s2 ? inside : 0.5f * (1.0f + inside));
+    glp = -a * ratio * w * inv_m;
+    const float v = values[i], r = ret[i];
+    const float u = v - r;
+    float gv;
+    if (clipped_value) {
+      const float dvp = v - vpred[i];
+      const float vc = vpred[i] + fminf(fmaxf(dvp, -clip), clip);
+      const float wv = vc - r;
+      const float ins = (dvp >= -clip && dvp <= clip) ? 1.0f : 0.0f;
+      const float uu = u * u, ww = wv * wv;
+      vl = 0.5f * fmaxf(uu, ww);
+      gv = uu > ww ? u : (uu < ww ? wv * ins : 0.5f * (u + wv * ins));
+    } else { vl = 0.5f * u * u; gv = u; }
+    g_values[i] = value_coef * gv * inv_m;
+  }
+  // block reductions: value loss, action loss, then d/dlogstd per action dim (also writes d/dmean)
+  auto block_sum = [&](float x) -> float {
+    red[threadIdx.x] = x;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float* P = part + (size_t)blockIdx.x * (3 + A);
+  const float svl = block_sum(vl), sal = block_sum(al);
+  if (threadIdx.x == 0) { P[0] = svl; P[1] = sal; P[2] = (float)(min(m - (int)(blockIdx.x * blockDim.x), (int)blockDim.x)); }
+  for (int j = 0; j < A; j++) {
+    float gls = 0.f;
+    if (on) {
+      const float e = __expf(-logstd[j]);
+      const float z = (action[(size_t)i * A + j] - mean[(size_t)i * A + j]) * e;
+      g_mean[(size_t)i * A + j] = glp * z * e;          // d logp / d mean_j = z / sigma
+      gls = glp * (z * z - 1.0f);                        // d logp / d logstd_j = z^2 - 1
+    }
+    const float s = block_sum(gls);
+    if (threadIdx.x == 0) P[3 + j] = s;
+  }
+}
+
 }  // namespace
 
 // ================================================================== host side
@@ -756,6 +828,21 @@ int solorl_compute_returns(const float* rewards, float* value_preds, const float
   HIP_TRY(hipSetDevice(device_id));
   hipLaunchKernelGGL(returns_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards, value_preds, masks,
                      next_value, returns, T, N, use_gae, gamma, gae_lambda);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int solorl_ppo_loss(const float* mean, const float* logstd, const float* values, const float* action, const float* old_logp,
+                    const float* adv, const float* vpred, const float* ret, int m, int A, float clip, float value_coef,
+                    int clipped_value, float* grad_mean, float* grad_values, float* partials, int device_id, void* stream) {
+  if (!mean || !logstd || !values || !action || !old_logp || !adv || !vpred || !ret || !grad_mean || !grad_values || !partials)
+    return fail(SOLORL_ERR_INVALID, "null array argument");
+  if (m < 1 || A < 1) return fail(SOLORL_ERR_INVALID, "m and A must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SOLORL_ERR_NODEVICE, "no HIP device available (no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(SOLORL_ERR_NODEVICE, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3((m + 255) / 256), dim3(256), 256 * sizeof(float), (hipStream_t)stream, mean, logstd, values,
+                     action, old_logp, adv, vpred, ret, m, A, clip, value_coef, clipped_value, grad_mean, grad_values, partials);
   HIP_TRY(hipGetLastError());
   return 0;
 }

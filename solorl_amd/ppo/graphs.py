@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as D
+from .fused import fused_ppo_loss
 from .ppo import PPO
 
 
@@ -81,9 +82,10 @@ class GraphedPPO(PPO):
     device tensor (update_linear_schedule fills it), otherwise the arithmetic is PPO.update's."""
 
     def __init__(self, actor_critic, clip_param, ppo_epoch, mini_batch_size, value_loss_coef, entropy_coef, lr=None,
-                 l2_coef=0.0, max_grad_norm=None, use_clipped_value_loss=True):
+                 l2_coef=0.0, max_grad_norm=None, use_clipped_value_loss=True, fused_loss=True):
         super().__init__(actor_critic, clip_param, ppo_epoch, mini_batch_size, value_loss_coef, entropy_coef, lr=lr,
                          l2_coef=l2_coef, max_grad_norm=max_grad_norm, use_clipped_value_loss=use_clipped_value_loss)
+        self.fused_loss = fused_loss
         dev = next(actor_critic.parameters()).device
         self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=torch.tensor(float(lr), device=dev),
                                           weight_decay=l2_coef, capturable=True)
@@ -110,16 +112,22 @@ class GraphedPPO(PPO):
             self._off += m
             obs_b, act_b, vpred_b, ret_b, old_lp_b = (s.index_select(0, idx) for s in self._src)
             adv_b = self._adv.index_select(0, idx)
-            values, logp, entropy = self.actor_critic.evaluate_actions(obs_b, act_b)
-            ratio = torch.exp(logp - old_lp_b)
-            action_loss = -torch.min(ratio * adv_b, torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * adv_b).mean()
-            if self.use_clipped_value_loss:
-                v_clipped = vpred_b + (values - vpred_b).clamp(-clip, clip)
-                value_loss = 0.5 * torch.max((values - ret_b).pow(2), (v_clipped - ret_b).pow(2)).mean()
+            if self.fused_loss:       # one HIP launch for log-prob, both losses and their head gradients (ppo/fused.py)
+                values, mean, logstd = self.actor_critic.heads(obs_b)
+                loss, value_loss, action_loss, entropy = fused_ppo_loss(mean, logstd, values, act_b, old_lp_b, adv_b, vpred_b, ret_b, clip,
+                                                                        self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
             else:
-                value_loss = 0.5 * (ret_b - values).pow(2).mean()
+                values, logp, entropy = self.actor_critic.evaluate_actions(obs_b, act_b)
+                ratio = torch.exp(logp - old_lp_b)
+                action_loss = -torch.min(ratio * adv_b, torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * adv_b).mean()
+                if self.use_clipped_value_loss:
+                    v_clipped = vpred_b + (values - vpred_b).clamp(-clip, clip)
+                    value_loss = 0.5 * torch.max((values - ret_b).pow(2), (v_clipped - ret_b).pow(2)).mean()
+                else:
+                    value_loss = 0.5 * (ret_b - values).pow(2).mean()
+                loss = value_loss * self.value_loss_coef + action_loss - entropy * self.entropy_coef
             self.bucket.zero()
-            (value_loss * self.value_loss_coef + action_loss - entropy * self.entropy_coef).backward()
+            loss.backward()
             self._stats += torch.stack([value_loss.detach(), action_loss.detach(), entropy.detach()])
 
         def opt_step():

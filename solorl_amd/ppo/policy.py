@@ -79,6 +79,12 @@ class Policy(nn.Module):
         action = mean if deterministic else mean + torch.exp(logstd) * torch.randn_like(mean)
         return value, action, gaussian_log_prob(action, mean, logstd)
 
+    def heads(self, inputs):
+        """(value, mean, logstd): what the fused loss kernel (ppo/fused.py) consumes."""
+        value, feat = self.base(inputs)
+        mean, logstd = self.pi_dist(feat)
+        return value, mean, logstd
+
     def get_value(self, inputs):
         return self.base.critic(inputs)
 

@@ -115,3 +115,35 @@ def test_hip_graph_update_world_size_2(gpu_device):
     res = [q.get(timeout=240) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert all(r[1] for r in res), res
+
+
+def test_fused_ppo_loss_matches_autograd(gpu_device):
+    """solorl_ppo_loss: losses and head gradients == the eager torch expression of agents/ppo/ppo.py:52-74."""
+    from solorl_amd.ppo.fused import fused_ppo_loss
+    from solorl_amd.ppo.policy import gaussian_log_prob, gaussian_entropy_mean
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    for m, A, clipped in [(1000, 12, True), (257, 8, True), (64, 12, False)]:
+        rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+        mean, logstd, values = rn(m, A).requires_grad_(), (0.3 * rn(A)).requires_grad_(), rn(m, 1).requires_grad_()
+        action = mean.detach() + torch.exp(logstd.detach()) * rn(m, A)
+        old_lp = gaussian_log_prob(action, mean.detach(), logstd.detach()) + 0.15 * rn(m, 1)      # ratios on both sides of the clip range
+        adv, vpred, ret = rn(m, 1), values.detach() + 0.2 * rn(m, 1), rn(m, 1)
+        clip, vc, ec = 0.1, 0.5, 0.01
+        logp = gaussian_log_prob(action, mean, logstd)
+        ratio = torch.exp(logp - old_lp)
+        al = -torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv).mean()
+        if clipped:
+            v_c = vpred + (values - vpred).clamp(-clip, clip)
+            vl = 0.5 * torch.max((values - ret).pow(2), (v_c - ret).pow(2)).mean()
+        else:
+            vl = 0.5 * (ret - values).pow(2).mean()
+        ent = gaussian_entropy_mean(mean, logstd)
+        (vl * vc + al - ent * ec).backward()
+        ref = [x.grad.clone() for x in (mean, logstd, values)]
+        for x in (mean, logstd, values): x.grad = None
+        loss, vl2, al2, ent2 = fused_ppo_loss(mean, logstd, values, action, old_lp, adv, vpred, ret, clip, vc, ec, clipped)
+        loss.backward()
+        assert torch.allclose(vl2, vl, rtol=1e-5, atol=1e-6) and torch.allclose(al2, al, rtol=1e-5, atol=1e-6) and torch.allclose(ent2, ent)
+        for a, b in zip((mean.grad, logstd.grad, values.grad), ref):
+            assert torch.allclose(a, b, rtol=2e-4, atol=1e-7), (a - b).abs().max()
