@@ -7,9 +7,9 @@
 //   (solo.py:186-222) -> A7 reward (baseEnv.py:91-157) -> A8 termination (baseEnv.py:162-180)
 //   -> A1 terminal reward override / info (baseEnv.py:52-66) -> A2/A9 reset (baseEnv.py:70-82).
 //
-// Layout: one env per lane, 64 envs per workgroup (one wavefront), struct-of-arrays state in HBM
-// (field-major: every load/store of a field is one coalesced 256-byte access per wave), constraint
-// rows of the contact solve in LDS, everything else in VGPRs.
+// Layout: struct-of-arrays state in HBM (field-major).  Team mode (default): 16 lanes per env, 4 envs per
+// wavefront, per-env context and constraint rows in LDS, the PGS sweep register-resident (dynamics.hpp).
+// Lane mode (SOLORL_TEAM=0): one env per lane, 64 envs per workgroup, rows in LDS, the rest in VGPRs.
 //
 // Reset is O(1): `reset = fixed pose + K zero-torque control steps` is a pure function of K
 // (5..11), so the post-settle states are simulated ONCE at create time by this same kernel
@@ -236,14 +236,11 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
 }
 
 // ---------------------------------------------------------------- the hot kernel
-// One env per lane, `blockDim.x` (= envs per wavefront, 1..64) lanes per workgroup.  The kernel is
-// latency/issue bound and independent per env, so for small batches the host launches MORE waves
-// with FEWER active lanes each (one wave per SIMD: 4096 envs -> 1024 waves of 4 lanes) instead of
-// 64 full waves on a 1024-SIMD chip.
-// TEAM = false (lane mode): one env per lane, 64 envs per wavefront -- best throughput for large batches.
-// TEAM = true  (team mode): 16 lanes per env, 4 envs per wavefront; the row leader (t == 0) runs the
-// env logic and the dynamics phases, the whole row shares the PGS sweep (dynamics.hpp) -- shortest
-// latency for small batches, where the launch lasts as long as the heaviest env's sequential sweep.
+// TEAM = true  (team mode, default): 16 lanes per env, 4 envs per wavefront.  The team leader (t == 0) runs the env
+//   logic; history / observation / impulse cache are moved by all 16 lanes; the sub-steps are substep_team
+//   (dynamics.hpp).  With 4096 envs there is one wavefront per SIMD and the launch lasts as long as its heaviest
+//   wave, so everything on that wave's critical path is spread over the team's lanes.
+// TEAM = false (lane mode, SOLORL_TEAM=0): one env per lane, 64 envs per wavefront.
 template <typename T, int ROBOT, bool TEAM>
 SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
                   const Layout& L, int N, const EnvParams& P, const PhysParams<T>& pp, const float* __restrict__ actions,
@@ -698,7 +695,7 @@ struct solorl_env {
   double goal_radius = 2.0;
   int epw = 64;   // envs per wavefront (lanes per workgroup)
   bool spread = true;
-  bool team = false;   // 16 lanes per env (small batches)
+  bool team = false;   // 16 lanes per env (set at create: default true)
 };
 
 namespace {
