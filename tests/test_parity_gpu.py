@@ -354,3 +354,31 @@ def test_ragged_batch_sizes(gpu_device, n):
         assert o.shape == (n, c.obs_dim) and torch.isfinite(o).all()
         dq += [np.abs(np.array(env.get_state(i).q) - np.array(orc.get_state(i).q)).max() for i in range(n)]
     assert np.median(dq) < 1e-4 and np.max(dq) < 5e-2
+
+
+def test_full_state_matches_oracle_resynced(gpu_device):
+    """Every state field after one resynced control step, not only the joint angles: base pose and twist, joint
+    rates and the cached normal impulses of the 20 collision primitives (medians: single envs may hit a
+    non-convergent friction configuration of the 50-sweep PGS)."""
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    N = 64
+    env, orc = make(c, N, seed=8)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(4)
+    err = {k: [] for k in ("pos", "quat", "lin_vel", "ang_vel", "qd", "lambda_prev")}
+    for t in range(20):
+        for i in range(N):
+            orc.set_state(i, env.get_state(i))
+        a = (0.5 * rng.uniform(-1, 1, size=(N, 12))).astype(np.float32)
+        _, _, done, _ = env.step(torch.from_numpy(a).cuda())
+        _, _, odone, _ = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy()
+        for i in range(N):
+            if done[i] or odone[i]:
+                continue
+            sg, so = env.get_state(i), orc.get_state(i)
+            for k in err:
+                err[k].append(np.abs(np.array(getattr(sg, k)) - np.array(getattr(so, k))).max())
+    tol = dict(pos=2e-7, quat=1e-6, lin_vel=5e-6, ang_vel=5e-5, qd=5e-4, lambda_prev=5e-6)   # measured medians: 7e-9, 5e-8, 1e-7, 1e-6, 2e-5, 8e-8
+    for k, v in err.items():
+        assert len(v) > 1000 and np.median(v) < tol[k], (k, np.median(v))
