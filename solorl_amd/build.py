@@ -24,6 +24,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
            "-I" + os.path.join(ROOT, "include"), "-o", LIB + ".tmp", SRC[0]]
     cmd[1:1] = ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
+    cmd[1:1] = os.environ.get("SOLORL_BUILD_FLAGS", "").split()                                 # dev experiments
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
