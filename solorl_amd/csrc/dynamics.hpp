@@ -564,7 +564,7 @@ template <typename T> SD LegSign<T> leg_sign(int L) {
     else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
     else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {   // (by reference:
+SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {   // (by reference:
                                                                      // ten more live argument registers made this phase spill 101 VGPRs)
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
@@ -1041,7 +1041,7 @@ SNI int cap_contacts(CH ch, int mask) {
 // twelve base points on lanes 4..15, joint-limit tests one joint per lane; masks are OR-reduced over the team.
 // The leader then records the counts and starts the articulated-inertia accumulation with the base link.
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, bool valid, bool lead) {
+SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, bool valid, bool lead) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ, NQ = RB::NQ, ST = NJ + 1;
   SubCtx<T, ROBOT>& C = ch.get();
@@ -1100,6 +1100,7 @@ SNI void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, b
   lbits = team_or16(lbits);
   if (__popc(mask) > MAX_CONTACTS) {
     if (lead) C.mask = cap_contacts<T, ROBOT, CH>(ch, mask);
+    TEAM_SYNC();
     mask = C.mask;                                     // (LDS: written by the leader just above, same wave)
   }
   const int nl = __popc(lbits);
@@ -1153,7 +1154,7 @@ SD void team_sum_base(CH ch, int t) {
 // leader: base solve, then publish what the other lanes need (bc: Lam 36, u*_base 6, padded leg rates 12, -a0 6... see TeamRows)
 // TEAMQ = true: the leg rates u*_leg (C.qds, bc[42..]) are left to phase_legrates_team (one joint per lane).
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_base_lead(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds) {
+SNI_SCALAR void phase_base_lead(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
@@ -1203,7 +1204,7 @@ template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt
 
 // all 16 lanes: lane t finishes rows t, t+16 and writes them as team records (layout: TeamRows)
 template <typename T, int ROBOT, typename LDS>
-SNI void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
+SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
   const int col = lds.lane;
   int nlt, nc, ncmax, anylim;
@@ -1241,7 +1242,7 @@ SNI void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
   const T mu0 = lds.A(t, LDS::A_MU);
   int meta1 = 0; T mu1 = T(1);
   if (two) { lds.load_core(r1, c1); meta1 = (int)lds.A(r1, LDS::A_META); mu1 = lds.A(r1, LDS::A_MU); }
-  auto emit = [&](int r, const T (&c)[ROW_CORE], int meta, T mu) {
+  auto emit = [&](int r, const T (&c)[ROW_CORE], int meta, T mu) __attribute__((always_inline)) {
     const int leg = (meta >> 5) & 3;
     const T* ql = bc + 42 + leg * 3;
     SV<T> W; T rhs, dinv;
@@ -1451,7 +1452,7 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
 // apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.
 // Reads the sweep's results straight from the team arrays (accumulators in hdr / y, impulses in lam).
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS lds, int t, bool valid,
+SNI_SCALAR void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS lds, int t, bool valid,
                               bool lead) {
   using RB = Robot<ROBOT>;
   using TRW = TeamRows<T, LDS>;

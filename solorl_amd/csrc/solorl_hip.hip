@@ -59,6 +59,7 @@ Layout make_layout(int n, int D, int H) {
 struct EnvParams {
   int task, control, frame_skip, episode_length, hold_torque, disable_termination;
   int settle_min, nsettle;
+  int lds_poison_on; unsigned lds_poison;     // test hook, see step_body
   unsigned seed_lo, seed_hi; long long id0;
   double kp, kd, max_torque, reward_dt, goal_radius;
 };
@@ -264,6 +265,17 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   if (!valid) e = (idx_t)N - 1;           // team mode keeps every lane alive for the wave-level exchanges
   const bool lead = valid && t == 0;
   LDS lds; lds.lanes = EPB; lds.lane = col;
+  if constexpr (TEAM) {
+    // test hook (SOLORL_POISON_LDS=<word>, read at create): pre-fill the whole dynamic LDS.  Two runs with different
+    // fill words (NaN vs 0) must agree bitwise -- anything read before it is written in the launch breaks that
+    // (tests/test_parity_gpu.py::test_no_lds_read_before_write; this is how a lane hand-off race was found)
+    if (P.lds_poison_on) {
+      using TC = TeamCtx<T, ROBOT, LDS>;
+      unsigned* w = reinterpret_cast<unsigned*>(solo_smem);
+      for (unsigned k = threadIdx.x; k < TC::bytes / 4; k += 64) w[k] = P.lds_poison;
+      __syncthreads();
+    }
+  }
   idx_t env = 0;
   Env<T, NQ> E;
   if (TEAM ? valid : true) env = (idx_t)si[(idx_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
@@ -302,6 +314,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #pragma unroll
       for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
     }
+    TEAM_SYNC();
     if (valid && L.H > 0) {
 #pragma unroll
       for (int k = 0; k < HK; k++) {
@@ -334,6 +347,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
 #endif
     if (lead) ch.get().ps = E.ps;
+    TEAM_SYNC();
     // warm-start impulse cache: HBM -> LDS once per step (a global load/store per sub-step left a memory round
     // trip exposed at every phase boundary: the non-inlined calls wait for all outstanding VMEM)
     if (valid) for (int p = t; p < NPRIM; p += 16) ch.get().lamp[p] = sf[(idx_t)(L.lam + p) * N + e];
@@ -453,6 +467,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   }   // lead
   if constexpr (TEAM) {
     // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older], element d on lane d mod 16
+    TEAM_SYNC();
     team_obs = __shfl(team_obs, 0, 16);
     if (valid && team_obs) {
       const T* stage = TeamRows<T, LDS>::bc(col);
@@ -696,6 +711,7 @@ struct solorl_env {
   int epw = 64;   // envs per wavefront (lanes per workgroup)
   bool spread = true;
   bool team = false;   // 16 lanes per env (set at create: default true)
+  int lds_poison_on = 0; unsigned lds_poison = 0;   // SOLORL_POISON_LDS test hook
 };
 
 namespace {
@@ -708,6 +724,7 @@ EnvParams make_env_params(const solorl_env* h) {
   P.settle_min = c.settle_min; P.nsettle = c.settle_max - c.settle_min + 1;
   P.seed_lo = (unsigned)h->seed; P.seed_hi = (unsigned)(h->seed >> 32); P.id0 = h->id0;
   P.kp = c.kp; P.kd = c.kd; P.max_torque = c.max_torque; P.reward_dt = c.reward_dt; P.goal_radius = h->goal_radius;
+  P.lds_poison_on = h->lds_poison_on; P.lds_poison = h->lds_poison;
   return P;
 }
 template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
@@ -886,6 +903,7 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     if (const char* ev = getenv("SOLORL_SPREAD")) h->spread = atoi(ev) != 0;
     h->team = true;   // measured (tools/dev/bench_n.py): team mode wins at every batch size, 1k .. 262k envs; lane mode: SOLORL_TEAM=0
     if (const char* ev = getenv("SOLORL_TEAM")) h->team = atoi(ev) != 0;
+    if (const char* ev = getenv("SOLORL_POISON_LDS")) { h->lds_poison_on = 1; h->lds_poison = (unsigned)strtoul(ev, nullptr, 0); }
     h->epw = epw;
   }
   auto cleanup = [&](int code) { solorl_destroy(h); return code; };

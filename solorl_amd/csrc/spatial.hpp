@@ -12,6 +12,14 @@
 #include <hip/hip_runtime.h>
 #define SD __device__ __forceinline__
 #define SNI __device__ __noinline__
+// serial (one-lane) phases: the packed-FP32 forms need aligned register pairs, and assembling those pairs cost a
+// third of the leg phase in v_mov (769 of 2 600 instructions); scalar FMAs are shorter there
+#define SNI_SCALAR __device__ __noinline__ __attribute__((target("no-packed-fp32-ops")))
+// Hand-off between lanes of a team through LDS INSIDE one function (one lane stores, others load): without it
+// the compiler may forward the stored value on the storing path and sink the others' load into the opposite
+// branch, which the SIMT lowering can run first (found with the NaN-poisoned-LDS build, tools/dev/zero_region.sh).
+// Hand-offs across the non-inlined phase calls need nothing: a call orders all memory operations.
+#define TEAM_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
 namespace solo {

@@ -6,6 +6,8 @@
 #include <type_traits>
 #define SD inline
 #define SNI static __attribute__((noinline))
+#define SNI_SCALAR SNI
+#define TEAM_SYNC() do {} while (0)
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }

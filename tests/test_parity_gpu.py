@@ -382,3 +382,29 @@ def test_full_state_matches_oracle_resynced(gpu_device):
     tol = dict(pos=2e-7, quat=1e-6, lin_vel=5e-6, ang_vel=5e-5, qd=5e-4, lambda_prev=5e-6)   # measured medians: 7e-9, 5e-8, 1e-7, 1e-6, 2e-5, 8e-8
     for k, v in err.items():
         assert len(v) > 1000 and np.median(v) < tol[k], (k, np.median(v))
+
+
+def test_no_lds_read_before_write(gpu_device):
+    """The same 450-step rollout (resets, joint limits, the 8-contact cap all occur) with the kernel's LDS pre-filled
+    with zeros and with NaNs (SOLORL_POISON_LDS test hook) must agree bitwise: nothing may be read before it is
+    written in the launch, and lane hand-offs through LDS must be ordered.  (A hand-off in the contact-cap path was
+    not: the compiler had sunk the readers' load into the branch opposite the leader's store.)"""
+    from solorl_amd.vec_env import SoloVecEnv
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    N = 4096
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    acts = torch.rand((32, N, 12), device="cuda:0", generator=g) * 2 - 1
+    outs = []
+    for word in ("0", "0x7fc00000"):
+        os.environ["SOLORL_POISON_LDS"] = word
+        try:
+            env = SoloVecEnv(c, N, device="cuda:0", seed=9)
+        finally:
+            del os.environ["SOLORL_POISON_LDS"]
+        env.reset()
+        acc = torch.zeros(N, device="cuda:0"); nan = 0
+        for t in range(450):
+            o, r, d, info = env.step_inplace(acts[t % 32])
+            acc += r
+        outs.append((o.clone(), acc.clone(), int(info["nan_reset"].sum())))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2] == 0
