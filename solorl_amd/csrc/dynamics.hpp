@@ -1302,8 +1302,9 @@ template <typename T> SD T team_red8(T x) {      // sum over the 8 lanes of a ha
 }
 
 template <typename T, typename LDS, int LIM, int NNS, int NFS>
-SNI void pgs_team_variant(int iterations, const LDS lds, int t) {
+SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
+  const int iterations = __builtin_amdgcn_readfirstlane(iterations_v);   // function arguments arrive in VGPRs: make the sweep loop scalar
   constexpr int LN = LDS::LANES, n = LIM + NNS + NFS;
   constexpr int S_N0 = 1, S_F0 = 1 + MAX_CONTACTS / 2;      // slot numbers of the first normal / friction slot
   static_assert(n >= 1, "empty sweeps are not instantiated");
