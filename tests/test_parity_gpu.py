@@ -408,3 +408,34 @@ def test_no_lds_read_before_write(gpu_device):
             acc += r
         outs.append((o.clone(), acc.clone(), int(info["nan_reset"].sum())))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2] == 0
+
+
+def test_rollout_statistics_match_oracle(gpu_device):
+    """No resynchronisation: 512 envs x 300 steps of the same random actions on the engine and on the oracle.
+    Individual trajectories separate (contact-rich rigid-body dynamics is chaotic, and the engine computes in
+    fp32), but the aggregate behaviour an RL algorithm sees must not: episode terminations, base height and the
+    distribution of step rewards agree within sampling noise (quantiles: the reward has heavy tails -- velocity
+    squared -- so its plain sum is dominated by a handful of events)."""
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    N, T = 512, 300
+    env, orc = make(c, N, seed=12)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(21)
+    acts = rng.uniform(-1, 1, size=(32, N, 12)).astype(np.float32)
+    g = dict(done=0, fell=0, z=0.0, rew=[]); o = dict(done=0, fell=0, z=0.0, rew=[])
+    for t in range(T):
+        a = acts[t % 32]
+        obs, rew, done, info = env.step(torch.from_numpy(a).cuda())
+        oobs, orew, odone, oinfo = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy(); rew = rew.cpu().numpy()[:, 0]
+        g["done"] += int(done.sum()); o["done"] += int(odone.sum())
+        g["rew"].append(rew[done == 0]); o["rew"].append(orew[odone == 0])        # (terminal steps carry the -10 / bonus)
+        g["fell"] += int((rew == -10).sum()); o["fell"] += int((orew == -10).sum())
+        g["z"] += float(obs[:, 0].mean()); o["z"] += float(oobs[:, 0].mean())
+    assert g["done"] > 2000 and abs(g["done"] - o["done"]) < 0.05 * o["done"], (g["done"], o["done"])
+    assert abs(g["fell"] - o["fell"]) < 0.05 * o["fell"], (g["fell"], o["fell"])
+    assert abs(g["z"] - o["z"]) < 0.05 * o["z"], (g["z"], o["z"])
+    rg, ro = np.concatenate(g["rew"]), np.concatenate(o["rew"])
+    for qt in (0.1, 0.25, 0.5, 0.75, 0.9):
+        a_, b_ = np.quantile(rg, qt), np.quantile(ro, qt)
+        assert abs(a_ - b_) < 0.1 * abs(b_) + 0.02, (qt, a_, b_)
