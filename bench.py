@@ -146,15 +146,37 @@ def main():
                 env.step_inplace(acts[t % R])
     except Exception:
         graph, launch = None, "eager"
-    barrier()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
+
+    def all_ranks(flag):            # collective AND, so that every rank takes the same path (same number of barriers)
+        if world > 1:
+            f = torch.tensor([1 if flag else 0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item())
+        return bool(flag)
+
+    if not all_ranks(graph is not None):
+        graph, launch = None, "eager"
+
+    def timed(run):
+        barrier()
+        t0 = time.perf_counter()
+        run()
+        barrier()
+        return time.perf_counter() - t0
+
+    def eager_steps():
         for t in range(args.steps):
             env.step_inplace(acts[t % R])
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    if graph is not None:
+        probe = env.get_state(0).rng_counter, env.get_state(0).timestep, float(env._obs.double().sum())
+        elapsed = timed(graph.replay)
+        after = env.get_state(0).rng_counter, env.get_state(0).timestep, float(env._obs.double().sum())
+        if not all_ranks(after != probe):   # a replay did nothing (capture did not see the launches): do not report it
+            launch = "eager"
+            elapsed = timed(eager_steps)
+    else:
+        elapsed = timed(eager_steps)
     if world > 1:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
