@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the hot path on N GPUs of one node.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
-rank per GPU).  A "step" = one pass of the hot path over one batch: solorl_step() on 4096
-Solo12 'walk' envs per GPU (configs/basic12.yaml with task overridden to walk: frame_skip 4,
-episode_length 400, num_history_stack 1, torque control) driven by a random policy
-(a ~ U(-1,1)^12, synthetic, resident in HBM before the timed region).  Envs shard across ranks with no
-data-path collective ("weak" scaling); the only collectives are the barrier and the max-reduce
-of the elapsed time the contract asks for.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  Under torch.distributed.run (WORLD_SIZE set) this process
+is one rank; started directly with --gpus N > 1 it first spawns the N ranks itself (before touching the GPU), relays
+rank 0's JSON line and exits with the children's status.
 
-Prints ONE JSON line with value = whole-job env-steps/s plus `roofline` (algorithmic bytes of
-SURVEY.md 8d / kernel time from HIP events on the launch stream) and `cpu_baseline` (the fp64
-oracle timed on the host cores on a bounded sample; rank 0, N=1 only).
+A "step" = one pass of the hot path over one batch: solorl_step() on 4096 Solo12 'walk' envs per GPU
+(configs/basic12.yaml with the task overridden to walk: frame_skip 4, episode_length 400, num_history_stack 1, torque
+control) driven by a random policy (a ~ U(-1,1)^12, synthetic, resident in HBM before the timed region).  Envs shard
+across ranks with no data-path collective ("weak" scaling); the only collectives of the headline measurement are the
+barrier and the max-reduce of the elapsed time.
+
+Protocol, independent of --warmup: an untimed burn-in of episode_length + 50 control steps brings the
+fall/reset distribution to its stationary regime, then W warm-up steps, then the K timed steps -- ONE HIP-graph
+replay bracketed by barrier + synchronize -- are repeated 5 times and the MEDIAN repeat is reported (each repeat is
+exactly K steps; max over ranks per repeat).  `roofline.kernel_ms_avg` comes from HIP events recorded on the launch
+stream around the SAME replays, so it can never exceed ms_per_step.
+
+Prints ONE JSON line: value = whole-job env-steps/s, `roofline` (algorithmic bytes of SURVEY.md 8d / that kernel time;
+HBM traffic, VALU issue rate and FP32 rate from the committed rocprofv3 PMC passes), `cpu_baseline` (the fp64 oracle
+timed on the host cores on a bounded sample, all cores and one thread; rank 0, N=1 only) and `ppo_loop` (the full PPO
+iteration of BASELINE config 3 with the README recipe; with N > 1 every optimizer step carries the 80 KB RCCL
+all-reduce of the flat gradient bucket).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,7 +36,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+EPISODE_LENGTH = 400
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0   # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32, 2 cycles each (a LONE wave sustains 4)
+REPEATS = 5
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def algorithmic_bytes_per_env_step(A, S, C, O, hist_state, n_dr=5, n_counters=2):
@@ -32,8 +50,43 @@ def algorithmic_bytes_per_env_step(A, S, C, O, hist_state, n_dr=5, n_counters=2)
     return 4 * (A + 2 * S + 2 * C + O + h_rw + 2) + 1
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """Oracle (fp64 CPU restatement, kind 'port') on a bounded sample of the same workload."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ppo-steps", type=int, default=400, help="rollout length of the PPO-loop leg (0 = skip); README: num_steps = episode_length")
+    ap.add_argument("--ppo-epoch", type=int, default=5, help="PPO epochs of that leg (README: 5)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single-GPU box: all ranks use cuda:0 and the gloo backend (numbers are meaningless)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` started directly: launch the N ranks as children (torch.distributed.run) BEFORE this
+    process touches the GPU, relay rank 0's JSON line, fail if any child fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stdout.write(p.stdout)
+        sys.stderr.write("bench.py: %d-rank run failed (exit code %d, %s)\n" % (args.gpus, p.returncode, "no result line" if line is None else "result line present"))
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def cpu_baseline(cfg, budget_s=10.0):
+    """Oracle (fp64 CPU restatement, kind 'port') on a bounded sample of the same workload: all granted cores
+    (OpenMP over envs) and a single thread."""
     import numpy as np
     from oracle.oracle_py import Oracle
     try:
@@ -41,41 +94,56 @@ def cpu_baseline(cfg, budget_s=12.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = min(cores, int(os.environ.get("SOLORL_CPU_THREADS", "64")))
-    N = 16 * cores
-    orc = Oracle(cfg, N, seed=1, threads=cores)
-    orc.reset()
-    rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, size=(8, N, orc.A))
-    orc.step(acts[0])
-    t0 = time.perf_counter(); steps = 0
-    while True:
-        orc.step(acts[steps % 8]); steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or steps >= 2000:
-            break
-    return {"value": N * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d Solo12-walk envs x %d control steps, random policy, OpenMP over envs (%.1f s)" % (N, steps, el)}
+
+    def run(threads, N, budget):
+        orc = Oracle(cfg, N, seed=1, threads=threads)
+        orc.reset()
+        rng = np.random.default_rng(0)
+        acts = rng.uniform(-1, 1, size=(8, N, orc.A))
+        orc.step(acts[0])
+        t0 = time.perf_counter(); steps = 0
+        while True:
+            orc.step(acts[steps % 8]); steps += 1
+            el = time.perf_counter() - t0
+            if el > budget or steps >= 2000:
+                break
+        return N * steps / el, steps, el
+
+    v, steps, el = run(cores, 16 * cores, budget_s)
+    v1, steps1, el1 = run(1, 16, budget_s / 2)
+    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d Solo12-walk envs x %d control steps, random policy, OpenMP over envs (%.1f s)" % (16 * cores, steps, el),
+            "single_thread": {"value": v1, "unit": "env-steps/s", "cores": 1,
+                              "sample": "16 envs x %d control steps (%.1f s)" % (steps1, el1)}}
 
 
-def ppo_leg(env, dev, world, T):
-    """One PPO iteration with the README hyper-parameters (lr 2.5e-4, entropy 0.01, clip 0.1, GAE,
-    ppo-epoch 5 scaled to 1 epoch here, 50 mini-batches): rollout of T steps + returns + update, both loops
-    replayed from HIP graphs (solorl_amd/ppo/graphs.py) that were captured in an untimed first iteration."""
+def ppo_leg(env, dev, world, T, epochs):
+    """One PPO iteration with the README recipe (lr 2.5e-4, entropy 0.01, clip 0.1, GAE, `epochs` PPO epochs, 50
+    mini-batches per epoch, rollout length T): rollout + returns + update, both loops replayed from HIP graphs
+    (solorl_amd/ppo/graphs.py) captured in an untimed first iteration.  world > 1: one flat-bucket all-reduce per
+    optimizer step (agents/ppo/ppo.py:72-77 is where the reference would need it)."""
     import torch
+    import torch.distributed as dist
     from solorl_amd.ppo import Policy, RolloutStorage
     from solorl_amd.ppo.graphs import GraphedPPO, GraphedRollout
     N = env.nenvs
     torch.manual_seed(1)
     pol = Policy(env.observation_space.shape, env.action_space, None, {"hidden_size": 64}).to(dev)
-    agent = GraphedPPO(pol, 0.1, 1, max(T * N // 50, 1), 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
+    mb = max(T * N // 50, 1)
+    agent = GraphedPPO(pol, 0.1, epochs, mb, 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
     st = RolloutStorage(T, N, env.observation_space.shape, env.act_dim, dev)
     st.obs[0].copy_(env.get_observation())
     with torch.no_grad():
         pol.act(st.obs[0]); pol.get_value(st.obs[0])          # library workspaces before capture
     roll = GraphedRollout(env, pol, st, T)
 
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     def iteration():
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sync(); t0 = time.perf_counter()
         roll()
         torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
         with torch.no_grad():
@@ -83,27 +151,34 @@ def ppo_leg(env, dev, world, T):
         st.compute_returns(nv, True, 0.99, 0.95)
         agent.update(st)
         st.reset()
-        torch.cuda.synchronize()
+        sync()
         return t_roll, time.perf_counter() - t0
 
     iteration()                     # captures both graphs (and trains one step)
     t_roll, t_all = iteration()
-    return {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
-            "ppo_epoch": 1, "mini_batches": 50,
-            "note": "policy forward + env.step + storage per step, then GAE + one PPO epoch; rollout and mini-batch step replayed from HIP graphs"}
+    if world > 1:
+        tt = torch.tensor([t_roll, t_all], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_roll, t_all = tt.tolist()
+    out = {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
+           "ppo_epoch": epochs, "mini_batches_per_epoch": 50, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
+           "note": "policy forward + env.step + storage per step, then GAE + PPO epochs; rollout and mini-batch step replayed from HIP graphs"}
+    if world > 1:                   # the collective of the data-parallel PPO step, timed on its own
+        reps = 50
+        sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            agent.bucket.all_reduce_mean()
+        sync()
+        out["grad_allreduce"] = {"bytes": agent.bucket.flat.numel() * 4, "us_per_call": 1e6 * (time.perf_counter() - t0) / reps,
+                                 "calls_per_update": out["optimizer_steps"], "backend": dist.get_backend()}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ppo-steps", type=int, default=64, help="rollout length of the auxiliary PPO-loop leg (0 = skip)")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="multi-rank rehearsal on a single-GPU box: all ranks use cuda:0 and the gloo backend (numbers are meaningless)")
-    args = ap.parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args, argv))        # nothing GPU-related has been imported or called in this process
 
     import torch
     import torch.distributed as dist
@@ -113,6 +188,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N --gpus N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
     if args.rehearse_on_one_gpu:
@@ -126,9 +204,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    N = args.envs_per_gpu
+    N, K = args.envs_per_gpu, args.steps
     cfg = default_config(ROBOT_SOLO12, TASK_WALK)
     cfg.num_history_stack = 1                      # configs/basic12.yaml
+    assert cfg.episode_length == EPISODE_LENGTH
     env = SoloVecEnv(cfg, N, device=dev, seed=1, env_id_offset=rank * N)
     env.reset()
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
@@ -140,7 +219,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for t in range(args.warmup):
+    def all_ranks(flag):            # collective AND, so that every rank takes the same path (same number of barriers)
+        if world > 1:
+            f = torch.tensor([1 if flag else 0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item())
+        return bool(flag)
+
+    burn_in = EPISODE_LENGTH + 50   # to the stationary fall/reset regime, whatever --warmup says
+    for t in range(burn_in + args.warmup):
         env.step_inplace(acts[t % R])
     # the K timed steps are one HIP-graph replay (K step-kernel nodes): the C-ABI launch is capturable and a graph
     # removes the ~5 us dispatch gap between consecutive launches; falls back to eager launches if capture fails
@@ -149,61 +236,57 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for t in range(args.steps):
+            for t in range(K):
                 env.step_inplace(acts[t % R])
     except Exception:
         graph, launch = None, "eager"
-
-    def all_ranks(flag):            # collective AND, so that every rank takes the same path (same number of barriers)
-        if world > 1:
-            f = torch.tensor([1 if flag else 0], device=dev)
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            return bool(f.item())
-        return bool(flag)
-
     if not all_ranks(graph is not None):
         graph, launch = None, "eager"
 
+    def eager_steps():
+        for t in range(K):
+            env.step_inplace(acts[t % R])
+
     def timed(run):
+        """exactly K steps: wall clock between barrier+synchronize on both sides, and HIP events on the launch stream
+        around the same work"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
-        run()
+        e0.record(); run(); e1.record()
         barrier()
-        return time.perf_counter() - t0
-
-    def eager_steps():
-        for t in range(args.steps):
-            env.step_inplace(acts[t % R])
+        el = time.perf_counter() - t0
+        return el, e0.elapsed_time(e1) * 1e-3
 
     if graph is not None:
         probe = env.get_state(0).rng_counter, env.get_state(0).timestep, float(env._obs.double().sum())
-        elapsed = timed(graph.replay)
+        first = timed(graph.replay)
         after = env.get_state(0).rng_counter, env.get_state(0).timestep, float(env._obs.double().sum())
         if not all_ranks(after != probe):   # a replay did nothing (capture did not see the launches): do not report it
-            launch = "eager"
-            elapsed = timed(eager_steps)
-    else:
-        elapsed = timed(eager_steps)
-    if world > 1:
-        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-
-    # kernel time from HIP events on the launch stream (the engine launches on torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
-    for t, (a, b) in enumerate(ev):
-        a.record(); env.step_inplace(acts[t % R]); b.record()
-    torch.cuda.synchronize()
-    kms = sorted(a.elapsed_time(b) for a, b in ev)
-    k_avg = sum(kms) / len(kms)      # one step = sort + gather + step_kernel launches; the step kernel is >95 % of it
+            graph, launch = None, "eager"
+    run = graph.replay if graph is not None else eager_steps
+    walls, devs = [], []
+    for r in range(REPEATS):
+        el, dv = timed(run)
+        if world > 1:
+            t_ = torch.tensor([el, dv], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el, dv = t_.tolist()
+        walls.append(el); devs.append(dv)
+    order = sorted(range(REPEATS), key=lambda i: walls[i])
+    mid = order[REPEATS // 2]
+    elapsed, dev_elapsed = walls[mid], devs[mid]
+    k_avg = 1e3 * dev_elapsed / K                 # ms per launch inside the timed window (graph: includes the ~1 us node gaps)
 
     ppo = None
-    if args.ppo_steps > 0 and world == 1:   # (auxiliary leg, single GPU only: the scaling runs measure the headline metric)
-        # BASELINE config 3: the full PPO loop (rollout + GAE + clipped update) on the same engine
+    if args.ppo_steps > 0:
+        # BASELINE config 3 / 4: the full PPO loop (rollout + GAE + clipped update) on the same engine; never fatal
         try:
-            ppo = ppo_leg(env, dev, world, args.ppo_steps)
-        except Exception as ex:      # the auxiliary leg must never take the headline measurement down with it
+            ppo = ppo_leg(env, dev, world, args.ppo_steps, args.ppo_epoch)
+        except Exception as ex:
             ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            if world > 1:           # a failure on one rank must not leave the others in a collective
+                raise
 
     if rank == 0:
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
@@ -211,36 +294,44 @@ def main():
         achieved = bytes_step * N / (k_avg * 1e-3) / 1e9
         out = {
             "metric": "env-steps/s (whole node) Solo12 walk, 4096 envs/GPU",
-            "value": world * N * args.steps / elapsed, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": world * N * K / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "solo12_walk_%denvs_per_gpu_random_policy_sim_only" % N, "robot": "solo12",
-                       "task": "walk", "envs_per_gpu": N, "frame_skip": 4, "episode_length": 400,
-                       "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world, "launch": launch},
+                       "task": "walk", "envs_per_gpu": N, "frame_skip": 4, "episode_length": EPISODE_LENGTH,
+                       "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world, "launch": launch,
+                       "burn_in_steps": burn_in, "repeats": REPEATS, "statistic": "median of %d repeats of exactly %d steps" % (REPEATS, K)},
+            "repeats_ms_per_step": [1e3 * w / K for w in walls],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "step_kernel_team<float,solo12>", "kernel_ms_avg": k_avg, "kernel_ms_min": kms[0],
+                         "kernel": "step_kernel_team<float,solo12>", "kernel_ms_avg": k_avg,
+                         "kernel_ms_source": "HIP events around the median timed replay / steps",
                          "algorithmic_bytes_per_env_step": bytes_step,
-                         "note": "path is FP32-VALU issue / dependency bound (SURVEY 8d), see valu_issue; HBM fraction is small by construction"},
+                         "note": "path is FP32-VALU issue / dependency bound (SURVEY 8d), see valu_issue and fp32; HBM fraction is small by construction"},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(traffic_file):   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            prof = json.load(open(traffic_file))
-            out["roofline"]["traffic"] = prof["bytes_per_launch"]
+        if os.path.exists(TRAFFIC_FILE) and N == ENVS_PER_GPU:
+            # per-launch figures from the committed rocprofv3 --pmc passes (profiles/r02_pmc_*.txt), steady state, 4096 envs
+            prof = json.load(open(TRAFFIC_FILE))
+            rf = out["roofline"]
+            rf["traffic"] = prof.get("bytes_per_launch")
             if "valu_insts_per_launch" in prof:
-                # what actually bounds the kernel: VALU issue.  A SIMD issues one wave64 VALU instruction per 4 cycles
-                # (MI355X_MICROARCH.md: 256 CUs x 4 SIMD16); instruction count from the committed SQ_INSTS_VALU pass.
-                peak = 256 * 4 * 2.4e9 / 4.0
                 rate = prof["valu_insts_per_launch"] / (k_avg * 1e-3)
-                out["roofline"]["valu_issue"] = {"achieved_ginst_s": rate / 1e9, "peak_ginst_s": peak / 1e9, "frac": rate / peak,
-                                                 "valu_insts_per_launch": prof["valu_insts_per_launch"]}
+                rf["valu_issue"] = {"achieved_ginst_s": rate / 1e9, "peak_ginst_s": VALU_ISSUE_PEAK / 1e9, "frac": rate / VALU_ISSUE_PEAK,
+                                    "valu_insts_per_launch": prof["valu_insts_per_launch"],
+                                    "peak_note": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU (a lone wave sustains one per 4)"}
+            if "fp32_flops_per_launch" in prof:
+                fl = prof["fp32_flops_per_launch"] / (k_avg * 1e-3)
+                rf["fp32"] = {"achieved_tflops": fl / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TF, "frac": fl / 1e12 / FP32_VECTOR_PEAK_TF,
+                              "flops_per_launch": prof["fp32_flops_per_launch"], "flops_per_env_step": prof["fp32_flops_per_launch"] / N,
+                              "count": prof.get("fp32_flops_note", "")}
         if ppo is not None:
             out["ppo_loop"] = ppo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

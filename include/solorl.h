@@ -69,7 +69,7 @@ typedef struct solorl_config {
   int32_t settle_max;       /*        (baseEnv.py:79: randint(5,12) -> 5..11)                      */
   int32_t disable_termination; /* parity runs: never set done */
   int32_t precision;        /* SOLORL_PRECISION_*: arithmetic type of the HIP engine */
-  int32_t reserved0;
+  int32_t use_treadmill;    /* config 'use_treadmill' (simulation.py:24-26,45-77): friction strip, see treadmill_* below */
   double kp, kd;            /* config 'gains' (configs/basic_pd.yaml:6) */
   double max_torque;        /* solo.py:53 max_joint_torque = 3 */
   double sim_dt;            /* solo.py:22 scene_timestep = 1/240 */
@@ -82,6 +82,14 @@ typedef struct solorl_config {
   double max_velocity;      /* generalized velocity clamp 100 (K5) */
   double joint_limit;       /* +-10 rad (URDF; solo.py:109) */
   double goal_radius;       /* solo.py:141 goal_radius = 2.0 */
+  /* Treadmill (simulation.py:45-77): a static 50 x 2 zero heightfield = a 49 m x 1 m strip at z = 0 centred on
+   * y = +-treadmill_offset (sign redrawn at every reset, simulation.py:72-74), Bullet default friction 0.5; its
+   * velocity is set on a mass-0 body and has no effect.  Modelled as: a contact whose point lies on the strip
+   * (|y - y_strip| <= treadmill_half_width) gets friction link_mu * treadmill_friction and is NOT reported by the
+   * feet sensor, which only queries the plane body (solo.py:313-317). */
+  double treadmill_offset;      /* 0.49 (simulation.py:49) */
+  double treadmill_half_width;  /* 0.5: (numHeightfieldColumns - 1) / 2 grid units */
+  double treadmill_friction;    /* 0.5: Bullet's default lateral friction of the heightfield body */
 } solorl_config;
 
 /* Struct-of-arrays info block (replaces the per-env dicts of baseEnv.py:62-66).  Every pointer is
@@ -98,7 +106,15 @@ typedef struct solorl_info_soa {
   float*   dr_torque;        /* info['dr/torque_rew'] */
   float*   dr_balance;       /* info['dr/roll_pitch_balance_rew'] */
   float*   dr_progress;      /* info['dr/progress_rew'] */
+  /* Finished-episode accumulators, field-major [SOLORL_EPSTAT_FIELDS][num_envs], or NULL: at every env-step that ends
+   * an episode the engine ADDS that episode's values to the env's own column (no atomics: deterministic); the caller
+   * reduces over envs and zeroes the block whenever it logs.  Replaces iterating N info dicts per step
+   * (agents/ppo/train.py:90-100).  Fields: 0 episodes finished, 1 sum info['episode_reward'], 2 sum
+   * info['episode_length'], 3 sum info['success'], 4..8 sums of the info['dr/...'] terms (stand, joint_pose, torque, balance,
+   * progress), 9 episodes ended by the non-finite-state guard (not counted in 0..8). */
+  float*   ep_stats;
 } solorl_info_soa;
+#define SOLORL_EPSTAT_FIELDS 10
 
 /* Physical + bookkeeping state of ONE env in a fixed, precision-independent (double) layout;
  * used by solorl_get_state/solorl_set_state (HOST pointers) for parity tests. */
@@ -112,7 +128,11 @@ typedef struct solorl_env_state {
   double hist[2][SOLORL_STATE_MAX_OBS];        /* state_history, [0] = newest */
   double goal[2], potential, progress, goals_reached, env_goals_reached;
   double dr[5];                                /* stand, joint_pose, torque, balance, progress */
-  int32_t timestep, need_reset, contact_mask /* bit p: primitive p was in contact */, rng_counter;
+  double treadmill_y;                          /* centre line of the treadmill strip (+-treadmill_offset; 0 if unused) */
+  int32_t timestep, need_reset;
+  int32_t contact_mask;  /* bit p (0..19): primitive p was in contact in the last sub-step; bit 20+f: foot f's contact
+                          * was on the treadmill strip (hidden from the feet sensor) */
+  int32_t rng_counter;
 } solorl_env_state;
 
 typedef struct solorl_env solorl_env;

@@ -326,13 +326,18 @@ static void substep(oracle_env* E, int ei) {
     r->parent = -1; r->rhs = dist[p] + C->linear_slop; normal_row[a] = nr++;
   }
   int nnormal_end = nr;
+  /* treadmill (reference simulation.py:45-77; model: include/solorl.h treadmill_*): a contact whose point lies on
+   * the strip takes the strip's friction (Bullet combines by product) and is hidden from the feet sensor */
+  int on_strip[NP_MAX] = {0};
+  if (C->use_treadmill)
+    for (int a = 0; a < nact; a++) on_strip[act[a]] = fabs(P[act[a]][1] - s->treadmill_y) <= C->treadmill_half_width;
   for (int a = 0; a < nact; a++) {
     int p = act[a];
     for (int d = 0; d < 2; d++) {
       double t[3] = {d == 0, d == 1, 0};
       row_t* r = &rows[nr++]; memset(r, 0, sizeof *r);
       point_jacobian_row(E, s, &K, E->md->prims[p].link, P[p], t, r->J);
-      r->parent = normal_row[a]; r->mu = E->md->prims[p].friction;
+      r->parent = normal_row[a]; r->mu = E->md->prims[p].friction * (on_strip[p] ? C->treadmill_friction : 1.0);
     }
   }
   double dV[NV_MAX]; memset(dV, 0, sizeof dV);
@@ -373,6 +378,7 @@ static void substep(oracle_env* E, int ei) {
     s->lambda_prev[act[a]] = rows[normal_row[a]].lam;
     E->last_lambda[ei][act[a]] = rows[normal_row[a]].lam;
     s->contact_mask |= 1 << act[a];
+    for (int f = 0; f < 4; f++) if (on_strip[act[a]] && E->md->foot_prim[f] == act[a]) s->contact_mask |= 1 << (20 + f);
   }
 
   /* --- semi-implicit Euler position update with the new velocities (K1) */
@@ -395,8 +401,10 @@ static void substep(oracle_env* E, int ei) {
 }
 
 /* ------------------------------------------------------------------ env logic */
+/* SoloBase.get_feet_ground_contact, solo.py:310-323: contact points between the foot link and `ground_id`, the PLANE
+ * body -- a foot standing on the treadmill strip (its own body, simulation.py:59-64) is not reported (bit 20+f) */
 static int foot_contact(const oracle_env* E, const solorl_env_state* s, int f) {
-  return (s->contact_mask >> E->md->foot_prim[f]) & 1;
+  return ((s->contact_mask >> E->md->foot_prim[f]) & 1) && !((s->contact_mask >> (20 + f)) & 1);
 }
 
 /* SoloBase.get_current_state, reference solo.py:198-222 */
@@ -462,6 +470,13 @@ static void env_reset(oracle_env* E, int i) {
   memset(s, 0, sizeof *s);
   s->rng_counter = rc; s->goal[0] = g0; s->goal[1] = g1;
   s->pos[2] = 0.35; s->quat[3] = 1.0;                  /* solo.py:52,292-293 */
+  if (E->cfg.use_treadmill) {                          /* scene.reset -> Treadmill.reset, simulation.py:37-41,72-74: new side */
+    uint32_t rt[4];
+    uint64_t gidt = (uint64_t)(E->id0 + i);
+    oracle_philox((uint32_t)E->seed, (uint32_t)(E->seed >> 32), (uint32_t)gidt, (uint32_t)(gidt >> 32),
+                  (uint32_t)s->rng_counter++, 3u, rt);
+    s->treadmill_y = (rt[0] & 1u) ? E->cfg.treadmill_offset : -E->cfg.treadmill_offset;
+  }
   for (int hI = 0; hI < E->cfg.num_history_stack; hI++) current_state(E, s, s->hist[hI]);
   if (E->cfg.task == SOLORL_TASK_POINTGOAL) {
     sample_goal(E, i, s);   /* after the history fill, as solo.py:170-174: history keeps the old goal */

@@ -27,11 +27,12 @@ class SoloConfig(C.Structure):
         ("episode_length", C.c_int32), ("num_history_stack", C.c_int32), ("hold_torque", C.c_int32),
         ("use_urdf_inertia", C.c_int32), ("solver_iterations", C.c_int32), ("settle_min", C.c_int32),
         ("settle_max", C.c_int32), ("disable_termination", C.c_int32), ("precision", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("use_treadmill", C.c_int32),
         ("kp", C.c_double), ("kd", C.c_double), ("max_torque", C.c_double), ("sim_dt", C.c_double),
         ("reward_dt", C.c_double), ("gravity", C.c_double), ("erp", C.c_double),
         ("linear_slop", C.c_double), ("warmstart", C.c_double), ("damping", C.c_double),
         ("max_velocity", C.c_double), ("joint_limit", C.c_double), ("goal_radius", C.c_double),
+        ("treadmill_offset", C.c_double), ("treadmill_half_width", C.c_double), ("treadmill_friction", C.c_double),
     ]
 
     @property
@@ -60,7 +61,7 @@ class EnvState(C.Structure):
         ("tau", C.c_double * MAX_DOF), ("lambda_prev", C.c_double * MAX_PRIMS),
         ("hist", (C.c_double * MAX_OBS) * 2), ("goal", C.c_double * 2), ("potential", C.c_double),
         ("progress", C.c_double), ("goals_reached", C.c_double), ("env_goals_reached", C.c_double),
-        ("dr", C.c_double * 5), ("timestep", C.c_int32), ("need_reset", C.c_int32),
+        ("dr", C.c_double * 5), ("treadmill_y", C.c_double), ("timestep", C.c_int32), ("need_reset", C.c_int32),
         ("contact_mask", C.c_int32), ("rng_counter", C.c_int32),
     ]
 
@@ -69,7 +70,12 @@ class InfoSoA(C.Structure):
     """ctypes mirror of ``solorl_info_soa`` (device pointers)."""
     _fields_ = [(k, C.c_void_p) for k in (
         "timeout", "success", "nan_reset", "episode_length", "episode_reward", "goals_reached",
-        "dr_stand", "dr_joint_pose", "dr_torque", "dr_balance", "dr_progress")]
+        "dr_stand", "dr_joint_pose", "dr_torque", "dr_balance", "dr_progress", "ep_stats")]
+
+
+EPSTAT_FIELDS = 10      # SOLORL_EPSTAT_FIELDS
+EPSTAT_NAMES = ("episodes", "episode_reward", "episode_length", "success", "dr/stand_rew", "dr/joint_pose_rew",
+                "dr/torque_rew", "dr/roll_pitch_balance_rew", "dr/progress_rew", "nan_resets")
 
 
 def default_config(robot=ROBOT_SOLO12, task=TASK_WALK):
@@ -84,6 +90,7 @@ def default_config(robot=ROBOT_SOLO12, task=TASK_WALK):
     c.sim_dt, c.reward_dt, c.gravity = 1.0 / 240.0, 1.0 / 60.0, 9.81
     c.erp, c.linear_slop, c.warmstart, c.damping = 0.2, 1e-5, 0.85, 0.04
     c.max_velocity, c.joint_limit, c.goal_radius = 100.0, 10.0, 2.0
+    c.use_treadmill, c.treadmill_offset, c.treadmill_half_width, c.treadmill_friction = 0, 0.49, 0.5, 0.5
     return c
 
 
@@ -99,10 +106,10 @@ def config_from_dict(d, **overrides):
     Robot selection: ``solo12: True`` (configs/basic12.yaml:10) or the ``model_urdf`` basename
     (``solo12.urdf`` -> Solo12, ``solo.urdf`` -> Solo8); the absolute path of the reference's YAML
     (configs/basic.yaml:4 points into the author's home) is not opened -- the model tables are
-    compiled in.  ``use_treadmill`` / ``flat_ground: False`` are out of scope and
-    rejected loudly rather than silently ignored, except ``use_treadmill`` which degrades to the
-    flat plane with a warning-free no-op because the treadmill strip never touches the feet
-    sensor (documented in DESIGN.md).
+    compiled in.  ``use_treadmill: True`` (configs/basic.yaml:10) enables the friction strip of
+    simulation.py:45-77 (``solorl_config.treadmill_*``); as in the reference it only exists on flat
+    ground (simulation.py:9).  ``flat_ground: False`` (heightfield terrains, simulation.py:79-154) is
+    out of scope and rejected loudly.
     """
     d = dict(d)
     d.update(overrides)
@@ -124,6 +131,7 @@ def config_from_dict(d, **overrides):
     c.frame_skip = int(d.get("frame_skip", 4))
     c.episode_length = int(d["episode_length"])
     c.num_history_stack = int(d.get("num_history_stack", 0))
+    c.use_treadmill = 1 if d.get("use_treadmill", False) else 0        # baseEnv.py:13, simulation.py:9
     if not 0 <= c.num_history_stack <= 2:
         raise ValueError("num_history_stack must be 0..2")
     gains = d.get("gains", None)
@@ -132,7 +140,8 @@ def config_from_dict(d, **overrides):
             raise ValueError("control 'pd' needs gains: [Kp, Kd] (solo.py:240)")
         c.kp, c.kd = float(gains[0]), float(gains[1])
     for k in ("hold_torque", "use_urdf_inertia", "solver_iterations", "disable_termination", "settle_min",
-              "settle_max", "precision", "warmstart", "erp", "damping", "reward_dt", "goal_radius"):
+              "settle_max", "precision", "warmstart", "erp", "damping", "reward_dt", "goal_radius", "treadmill_offset",
+              "treadmill_half_width", "treadmill_friction"):
         if k in d:
             setattr(c, k, type(getattr(c, k))(d[k]))
     return c

@@ -62,7 +62,12 @@ template <> struct Robot<1> {
 template <typename T> struct PhysParams {
   T dt, gravity, erp, slop, warm, damping, vmax, qlim, inv_dt;
   int iterations;
+  int tm_on; T tm_hw, tm_mu;   // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
 };
+// bit 20+f of a sub-step's returned mask: foot f's contact lies on the treadmill strip (foot primitive = 13 + 2f)
+SD int strip_feet_bits(int smask) {
+  return (((smask >> 13) & 1) << 20) | (((smask >> 15) & 1) << 21) | (((smask >> 17) & 1) << 22) | (((smask >> 19) & 1) << 23);
+}
 
 template <typename T, int NQ> struct PhysState {
   V3<T> pos; T qx, qy, qz, qw; V3<T> v, w;
@@ -267,6 +272,7 @@ template <typename T, int ROBOT> struct SubCtx {
   V3<T> kneeP[4], footP[4];
   T dist[NPRIM];
   int mask, nc, nlim_total, nlim;
+  int smask; T tmy;                // treadmill: primitives whose support point lies on the strip; the strip's centre line
   ABI<T> Ibase; SV<T> pbase;
   ABI<T> Ileg[4]; SV<T> pleg[4];   // team mode: per-leg contributions, summed by the leader
   int limoff[4];                   // team mode: first joint-limit slot of each leg
@@ -326,13 +332,15 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     else { sincos_t(st.q[j], sn[j], cs[j]); C.sn[j] = sn[j]; C.cs[j] = cs[j]; }
   }
   T dist[NPRIM];
-  int mask = 0;
+  int mask = 0, smask = 0;
+  const T ty = st.pos.y - C.tmy;    // treadmill: a point P (relative to the base origin) is on the strip iff |ty + P.y| <= tm_hw
   static_for<12>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr solorl_prim_data PR = RB::MD.prims[p];
     static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
     dist[p] = st.pos.z + R0.c0.z * T(PR.center[0]) + R0.c1.z * T(PR.center[1]) + R0.c2.z * T(PR.center[2]);
     if (dist[p] < T(PR.margin)) mask |= 1 << p;
+    if (pp.tm_on && fabs(ty + R0.c0.y * T(PR.center[0]) + R0.c1.y * T(PR.center[1]) + R0.c2.y * T(PR.center[2])) <= pp.tm_hw) smask |= 1 << p;
   });
   static_for<4>([&](auto lc) {
     constexpr int L = decltype(lc)::value;
@@ -343,6 +351,8 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     constexpr double mk_ = RB::MD.prims[12 + 2 * L].margin, mf_ = RB::MD.prims[13 + 2 * L].margin;   // (constexpr: no run-time model loads)
     if (dist[12 + 2 * L] < T(mk_)) mask |= 1 << (12 + 2 * L);
     if (dist[13 + 2 * L] < T(mf_)) mask |= 1 << (13 + 2 * L);
+    if (pp.tm_on && fabs(ty + kneeP.y) <= pp.tm_hw) smask |= 1 << (12 + 2 * L);
+    if (pp.tm_on && fabs(ty + footP.y) <= pp.tm_hw) smask |= 1 << (13 + 2 * L);
   });
   if (__popc(mask) > MAX_CONTACTS) {   // keep the MAX_CONTACTS deepest (ties: lower primitive id)
     int keep = 0;
@@ -366,6 +376,7 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     nl += (pp.qlim - st.q[j] < T(LIMIT_WINDOW)) ? 1 : 0;
   }
   C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
+  C.smask = smask & mask;
   {
     int run = 0;
 #pragma unroll
@@ -532,8 +543,8 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
         });
 #pragma unroll
         for (int r = 0; r < 3; r++) Y[r] = Minv[r][0] * JL[0] + Minv[r][1] * JL[1] + Minv[r][2] * JL[2];
-        park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0), T(PR.friction),
-                 (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8));
+        park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0),
+                 T(PR.friction) * (((C.smask >> p) & 1) ? pp.tm_mu : T(1)), (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8));
       });
     }
   });
@@ -694,7 +705,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       const T pen = C.dist[p] + pp.slop;
       const T lam0 = pp.warm * C.lamp[p];
       const T fric = SEL4(T, lsg, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
-                          RB::MD.prims[18 + i].friction);
+                          RB::MD.prims[18 + i].friction) * (((C.smask >> p) & 1) ? pp.tm_mu : T(1));
       static_for<3>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
@@ -742,7 +753,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, const T* lam_pre
           constexpr int d = decltype(dc)::value;
           V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
           park_row(lds, d == 0 ? sn_ : sf_ + (d - 1), SV<T>{cross(P, u), u}, Z, Z, P, C.dist[p] + pp.slop,
-                   d == 0 ? lam0 : T(0), T(PR.friction), (d == 0 ? 0 : (sn_ | 128)) | (d << 8));
+                   d == 0 ? lam0 : T(0), T(PR.friction) * (((C.smask >> p) & 1) ? pp.tm_mu : T(1)), (d == 0 ? 0 : (sn_ | 128)) | (d << 8));
         });
       }
     });
@@ -1048,7 +1059,8 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   const PhysState<T, NQ>& st = C.ps;
   const M3<T> R0 = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
   const T pz = st.pos.z;
-  int bits = 0, lbits = 0;
+  const T ty = st.pos.y - C.tmy;    // treadmill: point P (relative to the base origin) is on the strip iff |ty + P.y| <= tm_hw
+  int bits = 0, lbits = 0, sbits = 0;
   V3<T> bP = mk(T(0), T(0), T(0)); T bdist = T(0), bfric = T(0);      // base lanes: their point, distance, friction
   if (valid && t < 4) {
     const int L = t;
@@ -1075,6 +1087,10 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     C.dist[12 + 2 * L] = dk; C.dist[13 + 2 * L] = df;
     if (dk < PRIMC(0, margin)) bits |= 1 << (12 + 2 * L);
     if (df < PRIMC(1, margin)) bits |= 1 << (13 + 2 * L);
+    if (pp.tm_on) {
+      if (fabs(ty + kneeP.y) <= pp.tm_hw) sbits |= 1 << (12 + 2 * L);
+      if (fabs(ty + footP.y) <= pp.tm_hw) sbits |= 1 << (13 + 2 * L);
+    }
 #undef PRIMC
 #undef LEGC
   } else if (valid) {
@@ -1090,6 +1106,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     bdist = pz + bP.z;
     C.dist[p] = bdist;
     if (bdist < mg) bits |= 1 << p;
+    if (pp.tm_on && fabs(ty + bP.y) <= pp.tm_hw) { sbits |= 1 << p; bfric *= pp.tm_mu; }
   }
   if (valid && t < NQ) {    // joint limits: bit 2j = lower window, 2j+1 = upper window (same order as the row slots)
     const T q = st.q[t];
@@ -1098,6 +1115,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   int mask = team_or16(bits);
   lbits = team_or16(lbits);
+  if (pp.tm_on) sbits = team_or16(sbits);     // (uniform branch)
   if (__popc(mask) > MAX_CONTACTS) {
     if (lead) C.mask = cap_contacts<T, ROBOT, CH>(ch, mask);
     TEAM_SYNC();
@@ -1120,6 +1138,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   if (!lead) return;
   C.R0 = R0;
   C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
+  C.smask = sbits & mask;
 #pragma unroll
   for (int L = 0; L < 4; L++) {
     const int run = __popc(lbits & ((1 << (2 * NJ * L)) - 1));
@@ -1543,7 +1562,7 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   SOLO_TICK(5);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
   SOLO_TICK(6);
-  return lead ? ch.get().mask : 0;
+  return lead ? (ch.get().mask | strip_feet_bits(ch.get().smask)) : 0;
 }
 #endif  // !SOLO_HOST_SHIM
 
@@ -1562,7 +1581,7 @@ SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, T* lam_prev, unsigne
   phase_base<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, lds);
   phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  return C.mask;
+  return C.mask | strip_feet_bits(C.smask);
 }
 
 }  // namespace solo

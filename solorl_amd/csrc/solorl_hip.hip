@@ -42,7 +42,7 @@ using idx_t = unsigned;   // device-side element indices: 32-bit (solorl_create 
 // field-major state layout (offsets in units of N elements)
 struct Layout {
   int n, D, H, NF;
-  int pos, quat, v, w, q, qd, lam, hist, goal, pot, prog, goals, egoals, dr, xyprev;
+  int pos, quat, v, w, q, qd, lam, hist, goal, pot, prog, goals, egoals, dr, xyprev, tmy;
 };
 enum { I_TIMESTEP = 0, I_MASK = 1, I_RNG = 2, I_NEEDRESET = 3, I_ENVID = 4, NI = 5 };   // I_ENVID: slot -> env id
 
@@ -51,7 +51,7 @@ Layout make_layout(int n, int D, int H) {
   L.n = n; L.D = D; L.H = H;
   L.pos = o; o += 3; L.quat = o; o += 4; L.v = o; o += 3; L.w = o; o += 3;
   L.q = o; o += n; L.qd = o; o += n; L.lam = o; o += NPRIM; L.hist = o; o += 2 * DMAX;
-  L.goal = o; o += 2; L.pot = o++; L.prog = o++; L.goals = o++; L.egoals = o++; L.dr = o; o += 5; L.xyprev = o; o += 2;
+  L.goal = o; o += 2; L.pot = o++; L.prog = o++; L.goals = o++; L.egoals = o++; L.dr = o; o += 5; L.xyprev = o; o += 2; L.tmy = o++;
   L.NF = o;
   return L;
 }
@@ -59,16 +59,21 @@ Layout make_layout(int n, int D, int H) {
 struct EnvParams {
   int task, control, frame_skip, episode_length, hold_torque, disable_termination;
   int settle_min, nsettle;
+  int use_treadmill; float tm_offset;         // treadmill: side redrawn at reset (simulation.py:72-74)
   int lds_poison_on; unsigned lds_poison;     // test hook, see step_body
   unsigned seed_lo, seed_hi; long long id0;
-  double kp, kd, max_torque, reward_dt, goal_radius;
+  double kp, kd, max_torque, reward_dt;
+  const double* dyn;     // device block of the handle's MUTABLE parameters ([0] = goal_radius): a by-value copy would be frozen
+                         // into a captured HIP graph (solorl_increment_curriculum between replays must be seen)
 };
+enum { DYN_GOAL_RADIUS = 0, NDYN = 4 };
 
 enum { MODE_STEP = 0, MODE_SETTLE = 1 };
 
 struct Outputs {
   float* obs; float* rew; unsigned char* done;
   unsigned char *timeout, *success, *nan_reset; int* ep_len; float *ep_rew, *goals, *dr0, *dr1, *dr2, *dr3, *dr4;
+  float* ep_stats;     // [SOLORL_EPSTAT_FIELDS][N] finished-episode accumulators (include/solorl.h), or null
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -99,7 +104,7 @@ template <typename T> SD void euler_zyx(T x, T y, T z, T w, T& roll, T& pitch, T
 
 template <typename T, int NQ> struct Env {
   PhysState<T, NQ> ps;
-  T goal[2], pot, prog, goals, egoals, dr[5], xyprev[2];
+  T goal[2], pot, prog, goals, egoals, dr[5], xyprev[2], tmy;
   int timestep, mask, rng;
 };
 
@@ -115,7 +120,7 @@ SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, idx
   E.goals = F(L.goals); E.egoals = F(L.egoals);
 #pragma unroll
   for (int k = 0; k < 5; k++) E.dr[k] = F(L.dr + k);
-  E.xyprev[0] = F(L.xyprev); E.xyprev[1] = F(L.xyprev + 1);
+  E.xyprev[0] = F(L.xyprev); E.xyprev[1] = F(L.xyprev + 1); E.tmy = F(L.tmy);
   E.timestep = si[(idx_t)I_TIMESTEP * N + e]; E.mask = si[(idx_t)I_MASK * N + e]; E.rng = si[(idx_t)I_RNG * N + e];
 }
 template <typename T, int NQ>
@@ -131,7 +136,7 @@ SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, idx_t N,
   F(L.goals, E.goals); F(L.egoals, E.egoals);
 #pragma unroll
   for (int k = 0; k < 5; k++) F(L.dr + k, E.dr[k]);
-  F(L.xyprev, E.xyprev[0]); F(L.xyprev + 1, E.xyprev[1]);
+  F(L.xyprev, E.xyprev[0]); F(L.xyprev + 1, E.xyprev[1]); F(L.tmy, E.tmy);
   si[(idx_t)I_TIMESTEP * N + e] = E.timestep; si[(idx_t)I_MASK * N + e] = E.mask; si[(idx_t)I_RNG * N + e] = E.rng;
 }
 
@@ -150,7 +155,8 @@ SD void current_state(const Env<T, Robot<ROBOT>::NQ>& E, int task, T (&cs)[DMAX]
 #pragma unroll
   for (int j = 0; j < NQ; j++) { cs[10 + j] = E.ps.q[j] * T(0.1); cs[10 + NQ + j] = E.ps.qd[j] * T(0.01); }   // (/10, /100: solo.py:208-209)
 #pragma unroll
-  for (int f = 0; f < 4; f++) cs[10 + 2 * NQ + f] = ((E.mask >> (13 + 2 * f)) & 1) ? T(1) : T(0);
+  for (int f = 0; f < 4; f++)    // solo.py:310-323: plane contacts only -- a foot on the treadmill strip (bit 20+f) is not reported
+    cs[10 + 2 * NQ + f] = (((E.mask >> (13 + 2 * f)) & 1) && !((E.mask >> (20 + f)) & 1)) ? T(1) : T(0);
   if (task == SOLORL_TASK_POINTGOAL) {
     cs[14 + 2 * NQ] = E.ps.pos.x * T(0.5); cs[15 + 2 * NQ] = E.ps.pos.y * T(0.5);
     cs[16 + 2 * NQ] = E.goal[0] * T(0.5); cs[17 + 2 * NQ] = E.goal[1] * T(0.5);
@@ -161,7 +167,7 @@ template <typename T, int NQ>
 SD void sample_goal(Env<T, NQ>& E, const EnvParams& P, long long gid) {   // solo.py:325-330
   unsigned r[4];
   philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)E.rng++, 1u, r);
-  T span = T(P.goal_radius - 1.0);
+  T span = T(P.dyn[DYN_GOAL_RADIUS] - 1.0);
   T x = T(1) + T((double)(r[0] >> 8) * (1.0 / 16777216.0)) * span;
   T y = T(1) + T((double)(r[1] >> 8) * (1.0 / 16777216.0)) * span;
   E.goal[0] = (r[2] & 1u) ? x : -x; E.goal[1] = (r[3] & 1u) ? y : -y;
@@ -176,13 +182,20 @@ SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L,
   int rng = E.rng;
   T g0 = E.goal[0], g1 = E.goal[1];
   Env<T, NQ> S;
-  // order of draws as the reference: goal (robot.reset), then the settle count (env.reset)
+  // order of draws as the reference: treadmill side (scene.reset inside robot.reset, solo.py:166-168), goal (robot.reset),
+  // then the settle count (env.reset)
+  int side = 0;
+  if (P.use_treadmill) {
+    unsigned rt[4];
+    philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)rng++, 3u, rt);
+    side = (rt[0] & 1u) ? 0 : 1;               // 0: strip centred on +offset, 1: on -offset (second half of the snapshot table)
+  }
   E.rng = rng;
   if (P.task == SOLORL_TASK_POINTGOAL) { sample_goal(E, P, gid); g0 = E.goal[0]; g1 = E.goal[1]; }
   rng = E.rng;
   unsigned r[4];
   philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)rng++, 2u, r);
-  const int k = (int)(r[0] % (unsigned)P.nsettle);
+  const int k = (int)(r[0] % (unsigned)P.nsettle) + side * P.nsettle;
   load_env(S, snf, sni, L, (idx_t)M, (idx_t)k);
   E = S;
   E.rng = rng; E.timestep = 0;
@@ -346,7 +359,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #ifdef SOLO_PHASE_TIMING
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
 #endif
-    if (lead) ch.get().ps = E.ps;
+    if (lead) { ch.get().ps = E.ps; ch.get().tmy = E.tmy; }
     TEAM_SYNC();
     // warm-start impulse cache: HBM -> LDS once per step (a global load/store per sub-step left a memory round
     // trip exposed at every phase boundary: the non-inlined calls wait for all outstanding VMEM)
@@ -368,7 +381,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #endif
   } else {
     SubCtx<T, ROBOT> C;
-    C.ps = E.ps;
+    C.ps = E.ps; C.tmy = E.tmy;
 #pragma unroll 1
     for (int ss = 0; ss < P.frame_skip; ss++) {
       const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
@@ -437,6 +450,16 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   if (out.dr2) out.dr2[env] = (float)E.dr[2];
   if (out.dr3) out.dr3[env] = (float)E.dr[3];
   if (out.dr4) out.dr4[env] = (float)E.dr[4];
+  if (done && out.ep_stats) {      // finished-episode accumulators, one column per env (agents/ppo/train.py:90-100)
+    float* s = out.ep_stats + env;
+    const idx_t NN = (idx_t)N;
+    if (nanr) s[9 * NN] += 1.0f;
+    else {
+      s[0] += 1.0f; s[NN] += (float)reward; s[2 * NN] += (float)E.timestep; s[3 * NN] += (float)su;
+#pragma unroll
+      for (int k = 0; k < 5; k++) s[(4 + k) * NN] += (float)E.dr[k];
+    }
+  }
 
   // ---- auto-reset (agents/ppo/envs.py:39) and observation
 #ifdef SOLO_PHASE_TIMING
@@ -526,12 +549,13 @@ __global__ void obs_kernel(const T* sf, const int* si, Layout L, int N, int task
 
 // initial pose of SoloBase.robot_specific_reset (solo.py:291-296) for every env of a buffer
 template <typename T>
-__global__ void init_pose_kernel(T* sf, int* si, Layout L, int N) {
+__global__ void init_pose_kernel(T* sf, int* si, Layout L, int N, T tmy) {
   const idx_t e = (idx_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (idx_t)N) return;
   for (int f = 0; f < L.NF; f++) sf[(idx_t)f * N + e] = T(0);
   sf[(idx_t)(L.pos + 2) * N + e] = T(0.35);
   sf[(idx_t)(L.quat + 3) * N + e] = T(1);
+  sf[(idx_t)L.tmy * N + e] = tmy;
   for (int k = 0; k < NI; k++) si[(idx_t)k * N + e] = 0;
   si[(idx_t)I_NEEDRESET * N + e] = 1;
   si[(idx_t)I_ENVID * N + e] = (int)e;
@@ -556,7 +580,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
   const int t = threadIdx.x, nt = blockDim.x;
   const int chunk = (N + nt - 1) / nt, lo = t * chunk, hi = lo + chunk < N ? lo + chunk : N;
   int c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = lo; i < hi; i++) { int k = __popc(si[(idx_t)I_MASK * N + i]); k = k > 8 ? 8 : k; c[k]++; }
+  for (int i = lo; i < hi; i++) { int k = __popc(si[(idx_t)I_MASK * N + i] & 0xFFFFF); k = k > 8 ? 8 : k; c[k]++; }
 #pragma unroll
   for (int k = 0; k < 9; k++) cnt[t][k] = c[k];
   __syncthreads();
@@ -572,7 +596,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
 #pragma unroll
   for (int k = 0; k < 9; k++) off[k] = base[k] + cnt[t][k];
   for (int i = lo; i < hi; i++) {
-    int k = __popc(si[(idx_t)I_MASK * N + i]); k = k > 8 ? 8 : k;
+    int k = __popc(si[(idx_t)I_MASK * N + i] & 0xFFFFF); k = k > 8 ? 8 : k;
     int d = 0;
 #pragma unroll
     for (int q = 0; q < 9; q++) if (q == k) d = off[q]++;
@@ -708,6 +732,7 @@ struct solorl_env {
   bool sort = true;
   uint64_t seed = 0; int64_t id0 = 0;
   double goal_radius = 2.0;
+  double* dyn = nullptr;   // device copy of the mutable parameters (EnvParams::dyn)
   int epw = 64;   // envs per wavefront (lanes per workgroup)
   bool spread = true;
   bool team = false;   // 16 lanes per env (set at create: default true)
@@ -723,8 +748,9 @@ EnvParams make_env_params(const solorl_env* h) {
   P.hold_torque = c.hold_torque; P.disable_termination = c.disable_termination;
   P.settle_min = c.settle_min; P.nsettle = c.settle_max - c.settle_min + 1;
   P.seed_lo = (unsigned)h->seed; P.seed_hi = (unsigned)(h->seed >> 32); P.id0 = h->id0;
-  P.kp = c.kp; P.kd = c.kd; P.max_torque = c.max_torque; P.reward_dt = c.reward_dt; P.goal_radius = h->goal_radius;
+  P.kp = c.kp; P.kd = c.kd; P.max_torque = c.max_torque; P.reward_dt = c.reward_dt; P.dyn = h->dyn;
   P.lds_poison_on = h->lds_poison_on; P.lds_poison = h->lds_poison;
+  P.use_treadmill = c.use_treadmill; P.tm_offset = (float)c.treadmill_offset;
   return P;
 }
 template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
@@ -732,6 +758,7 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   p.dt = (T)c.sim_dt; p.gravity = (T)c.gravity; p.erp = (T)c.erp; p.slop = (T)c.linear_slop; p.warm = (T)c.warmstart;
   p.damping = (T)c.damping; p.vmax = (T)c.max_velocity; p.qlim = (T)c.joint_limit; p.inv_dt = (T)(1.0 / c.sim_dt);
   p.iterations = c.solver_iterations;
+  p.tm_on = c.use_treadmill; p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
   return p;
 }
 
@@ -779,16 +806,21 @@ int dispatch_step(solorl_env* h, void* sf, int* si, int N, const float* actions,
 template <typename T> int build_snapshots_t(solorl_env* h) {
   // one scratch env simulated from the reset pose; its state after k = settle_min..settle_max
   // zero-torque control steps is copied into snapshot slot k - settle_min.
+  // With the treadmill the settle depends on which side the strip lies: a second set of snapshots (slots nsettle..) for -offset.
   T* tf = nullptr; int* ti = nullptr;
   HIP_TRY(hipMalloc(&tf, sizeof(T) * h->L.NF)); HIP_TRY(hipMalloc(&ti, sizeof(int) * NI));
-  hipLaunchKernelGGL(init_pose_kernel<T>, dim3(1), dim3(64), 0, 0, tf, ti, h->L, 1);
   Outputs none; memset(&none, 0, sizeof none);
-  for (int k = 1; k <= h->cfg.settle_max; k++) {
-    int rc = dispatch_step(h, tf, ti, 1, nullptr, none, MODE_SETTLE, 0);
-    if (rc) return rc;
-    if (k >= h->cfg.settle_min)
-      hipLaunchKernelGGL(copy_env_kernel<T>, dim3((h->L.NF + 63) / 64), dim3(64), 0, 0, (const T*)tf, (const int*)ti, 1, 0,
-                         (T*)h->snf, h->sni, h->M, k - h->cfg.settle_min, h->L.NF);
+  const int nsettle = h->cfg.settle_max - h->cfg.settle_min + 1;
+  for (int side = 0; side < (h->cfg.use_treadmill ? 2 : 1); side++) {
+    const T tmy = h->cfg.use_treadmill ? (T)(side == 0 ? h->cfg.treadmill_offset : -h->cfg.treadmill_offset) : T(0);
+    hipLaunchKernelGGL(init_pose_kernel<T>, dim3(1), dim3(64), 0, 0, tf, ti, h->L, 1, tmy);
+    for (int k = 1; k <= h->cfg.settle_max; k++) {
+      int rc = dispatch_step(h, tf, ti, 1, nullptr, none, MODE_SETTLE, 0);
+      if (rc) return rc;
+      if (k >= h->cfg.settle_min)
+        hipLaunchKernelGGL(copy_env_kernel<T>, dim3((h->L.NF + 63) / 64), dim3(64), 0, 0, (const T*)tf, (const int*)ti, 1, 0,
+                           (T*)h->snf, h->sni, h->M, side * nsettle + k - h->cfg.settle_min, h->L.NF);
+    }
   }
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipFree(tf)); HIP_TRY(hipFree(ti));
@@ -808,6 +840,7 @@ int check_cfg(const solorl_config* c) {
   if (c->solver_iterations < 1 || c->solver_iterations > 1000) return fail(SOLORL_ERR_INVALID, "solver_iterations out of range");
   if (c->use_urdf_inertia) return fail(SOLORL_ERR_INVALID, "use_urdf_inertia=1 is not implemented by the HIP engine (box inertia, K2, only)");
   if (!(c->sim_dt > 0) || !(c->goal_radius > 1.0)) return fail(SOLORL_ERR_INVALID, "sim_dt must be > 0 and goal_radius > 1");
+  if (c->use_treadmill && !(c->treadmill_half_width > 0 && c->treadmill_friction >= 0)) return fail(SOLORL_ERR_INVALID, "bad treadmill parameters");
   if (c->precision != SOLORL_PRECISION_F32 && c->precision != SOLORL_PRECISION_F64) return fail(SOLORL_ERR_INVALID, "bad precision");
   return 0;
 }
@@ -871,6 +904,7 @@ int solorl_default_config(solorl_config* c, int robot, int task) {
   c->kp = 5.0; c->kd = 0.2; c->max_torque = 3.0; c->sim_dt = 1.0 / 240.0; c->reward_dt = 1.0 / 60.0; c->gravity = 9.81;
   c->erp = 0.2; c->linear_slop = 1e-5; c->warmstart = 0.85; c->damping = 0.04; c->max_velocity = 100.0;
   c->joint_limit = 10.0; c->goal_radius = 2.0;
+  c->use_treadmill = 0; c->treadmill_offset = 0.49; c->treadmill_half_width = 0.5; c->treadmill_friction = 0.5;
   return 0;
 }
 
@@ -891,7 +925,7 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   h->O = h->D * (1 + cfg->num_history_stack);
   h->f64 = cfg->precision == SOLORL_PRECISION_F64; h->tsize = h->f64 ? 8 : 4;
   h->L = make_layout(h->n, h->D, cfg->num_history_stack);
-  h->M = cfg->settle_max - cfg->settle_min + 1;
+  h->M = (cfg->settle_max - cfg->settle_min + 1) * (cfg->use_treadmill ? 2 : 1);
   h->goal_radius = cfg->goal_radius;
   {
     // envs per wavefront.  Measured on MI355X (profiles/r01_notes.md): narrower waves do NOT help -- the
@@ -914,6 +948,11 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
   if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
   if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
   if (hipMalloc(&h->sni, sizeof(int) * NI * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
+  {
+    double dyn0[NDYN] = {h->goal_radius, 0.0, 0.0, 0.0};
+    if (hipMalloc(&h->dyn, sizeof dyn0) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc dyn"));
+    if (hipMemcpy(h->dyn, dyn0, sizeof dyn0, hipMemcpyHostToDevice) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMemcpy dyn"));
+  }
   h->sort = false;   // measured with the team-mode sweep (tools/dev/bench_sort.sh): the sort + gather launches cost more than the
                      // padding they save at every batch size (65 536 envs: 29.5 M vs 23.8 M env-steps/s); SOLORL_SORT=1 enables it
   if (const char* ev = getenv("SOLORL_SORT")) h->sort = atoi(ev) != 0 && num_envs >= 2;
@@ -923,8 +962,8 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     if (hipMalloc(&h->perm, sizeof(int) * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc perm"));
   }
   dim3 g((num_envs + 255) / 256), b(256);
-  if (h->f64) hipLaunchKernelGGL(init_pose_kernel<double>, g, b, 0, 0, (double*)h->sf, h->si, h->L, num_envs);
-  else hipLaunchKernelGGL(init_pose_kernel<float>, g, b, 0, 0, (float*)h->sf, h->si, h->L, num_envs);
+  if (h->f64) hipLaunchKernelGGL(init_pose_kernel<double>, g, b, 0, 0, (double*)h->sf, h->si, h->L, num_envs, 0.0);
+  else hipLaunchKernelGGL(init_pose_kernel<float>, g, b, 0, 0, (float*)h->sf, h->si, h->L, num_envs, 0.0f);
   rc = h->f64 ? build_snapshots_t<double>(h) : build_snapshots_t<float>(h);
   if (rc) return cleanup(rc);
   if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "device sync after create"));
@@ -942,6 +981,7 @@ int solorl_destroy(solorl_env* h) {
   if (h->sf2) hipFree(h->sf2);
   if (h->si2) hipFree(h->si2);
   if (h->perm) hipFree(h->perm);
+  if (h->dyn) hipFree(h->dyn);
   delete h;
   return 0;
 }
@@ -956,6 +996,7 @@ int solorl_dims(const solorl_env* h, int* obs_dim, int* act_dim, int* num_envs) 
 
 int solorl_reset(solorl_env* h, float* obs_out, void* stream) {
   if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   EnvParams P = make_env_params(h);
   dim3 g((h->N + 255) / 256), b(256);
@@ -977,12 +1018,13 @@ int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* rewa
   if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
   if (!h->reset_called) return fail(SOLORL_ERR_STATE, "env.reset() must be called before step");   // baseEnv.py:43
   if (!actions || !obs_out || !reward_out || !done_out) return fail(SOLORL_ERR_INVALID, "null array argument");
+  HIP_TRY(hipSetDevice(h->device));
   Outputs o; memset(&o, 0, sizeof o);
   o.obs = obs_out; o.rew = reward_out; o.done = done_out;
   if (info) {
     o.timeout = info->timeout; o.success = info->success; o.nan_reset = info->nan_reset; o.ep_len = info->episode_length;
     o.ep_rew = info->episode_reward; o.goals = info->goals_reached; o.dr0 = info->dr_stand; o.dr1 = info->dr_joint_pose;
-    o.dr2 = info->dr_torque; o.dr3 = info->dr_balance; o.dr4 = info->dr_progress;
+    o.dr2 = info->dr_torque; o.dr3 = info->dr_balance; o.dr4 = info->dr_progress; o.ep_stats = info->ep_stats;
   }
   if (h->sort) {   // re-sort the state by last contact count (stable), into the spare buffer
     hipStream_t st = (hipStream_t)stream;
@@ -998,6 +1040,7 @@ int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* rewa
 
 int solorl_get_observation(solorl_env* h, float* obs_out, void* stream) {
   if (!h || !obs_out) return fail(SOLORL_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   dim3 g((h->N + 255) / 256), b(256);
   const bool s12 = h->cfg.robot == SOLORL_ROBOT_SOLO12;
@@ -1014,7 +1057,14 @@ int solorl_get_observation(solorl_env* h, float* obs_out, void* stream) {
 
 int solorl_increment_curriculum(solorl_env* h, double value) {
   if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
-  if (h->cfg.task == SOLORL_TASK_POINTGOAL) h->goal_radius += value;   // solo.py:332-334
+  if (h->cfg.task != SOLORL_TASK_POINTGOAL) return 0;                  // solo.py:332-334 (assert task == 'pointgoal')
+  HIP_TRY(hipSetDevice(h->device));
+  // The kernels read goal_radius from the handle's device block, so launches already captured in a HIP graph see the
+  // new value at their next replay.  Host-synchronising (rare call: once per curriculum_schedule updates): every step
+  // enqueued before this call samples with the old radius, every later one with the new.
+  HIP_TRY(hipDeviceSynchronize());
+  h->goal_radius += value;
+  HIP_TRY(hipMemcpy(h->dyn + DYN_GOAL_RADIUS, &h->goal_radius, sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1052,6 +1102,7 @@ int solorl_get_state(solorl_env* h, int i, solorl_env_state* out) {
   out->goal[0] = f[L.goal]; out->goal[1] = f[L.goal + 1]; out->potential = f[L.pot]; out->progress = f[L.prog];
   out->goals_reached = f[L.goals]; out->env_goals_reached = f[L.egoals];
   for (int k = 0; k < 5; k++) out->dr[k] = f[L.dr + k];
+  out->treadmill_y = f[L.tmy];
   out->timestep = iv[I_TIMESTEP]; out->contact_mask = iv[I_MASK]; out->rng_counter = iv[I_RNG]; out->need_reset = iv[I_NEEDRESET];
   return 0;
 }
@@ -1072,7 +1123,7 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
   f[L.goal] = in->goal[0]; f[L.goal + 1] = in->goal[1]; f[L.pot] = in->potential; f[L.prog] = in->progress;
   f[L.goals] = in->goals_reached; f[L.egoals] = in->env_goals_reached;
   for (int k = 0; k < 5; k++) f[L.dr + k] = in->dr[k];
-  f[L.xyprev] = in->pos[0]; f[L.xyprev + 1] = in->pos[1];
+  f[L.xyprev] = in->pos[0]; f[L.xyprev + 1] = in->pos[1]; f[L.tmy] = in->treadmill_y;
   int iv[NI]; iv[I_TIMESTEP] = in->timestep; iv[I_MASK] = in->contact_mask; iv[I_RNG] = in->rng_counter; iv[I_NEEDRESET] = in->need_reset;
   iv[I_ENVID] = env_id;
   if (h->f64) {

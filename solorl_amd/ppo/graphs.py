@@ -33,23 +33,20 @@ def _side_stream_warmup(fn, iters=3):
 
 
 class GraphedRollout:
-    """One graph = num_steps x (policy.act, env.step, storage.append [, episode-stat samples])."""
+    """One graph = num_steps x (policy.act, env.step, storage.append).  Episode statistics need nothing here: the step
+    kernel accumulates them on the device (include/solorl.h `ep_stats`), replayed or not."""
 
-    def __init__(self, envs, actor_critic, storage, num_steps, stats=None, stat_every=8):
-        self.envs, self.ac, self.storage, self.T, self.stats = envs, actor_critic, storage, num_steps, stats
-        self.stat_every = stat_every
+    def __init__(self, envs, actor_critic, storage, num_steps):
+        self.envs, self.ac, self.storage, self.T = envs, actor_critic, storage, num_steps
         self.graph = None
-        self._samples = []
 
-    def _body(self, record):
+    def _body(self):
         st = self.storage
         assert st.step == 0, "graphed rollouts start at storage step 0"
         for step in range(self.T):
             with torch.no_grad():
                 value, action, logp = self.ac.act(st.obs[step])
             obs, reward, done, info = self.envs.step_inplace(action.contiguous())
-            if record is not None and step % self.stat_every == self.stat_every - 1:
-                record.append((done.bool(), {k: v.clone() for k, v in info.items()}))
             st.append(obs, action, logp, value, reward.unsqueeze(-1), (1.0 - done.float()).unsqueeze(-1))
 
     def _capturable(self):
@@ -62,19 +59,16 @@ class GraphedRollout:
     def __call__(self):
         if not self._capturable():
             from .train import rollout
-            return rollout(self.envs, self.ac, self.storage, self.T, self.stats)
+            return rollout(self.envs, self.ac, self.storage, self.T)
         if self.graph is None:
             # no warm-up replay of the body: the env must not be stepped twice.  Everything the body allocates
             # is allocated inside the capture (private pool); cuBLAS/hipBLASLt workspaces were created by the
             # eager policy calls that precede the first rollout (train(): reset + get_value warm-up).
             g = torch.cuda.CUDAGraph()
-            rec = [] if self.stats is not None else None
             with torch.cuda.graph(g):
-                self._body(rec)
-            self.graph, self._samples = g, rec or []
+                self._body()
+            self.graph = g
         self.graph.replay()
-        if self.stats is not None:
-            self.stats._pending = list(self._samples)      # static graph outputs, valid until the next replay
 
 
 class GraphedPPO(PPO):

@@ -5,15 +5,14 @@ training/train_ppo.py:9-45.
 Differences that come with the GPU engine (documented, not behavioural):
   * rollout, policy forward, storage and update all stay on one HIP device: no device->host->pickle
     ->Pipe round trip per step (agents/ppo/envs.py:189-196);
-  * episode statistics are reduced on the device from the SoA info tensors instead of iterating N
-    Python dicts per step (train.py:90-100) -- same quantities: episode_reward (last-step reward,
-    baseEnv.py:65), episode_length, success, dr/* sums;
+  * episode statistics are accumulated by the step kernel on the device at EVERY step (no sampling) instead of
+    iterating N Python dicts per step (train.py:90-100) -- same quantities: episode_reward (last-step reward,
+    baseEnv.py:65), episode_length, success, dr/* sums, as means over the episodes finished per log interval;
   * multi-GPU: one process per GPU (`python -m torch.distributed.run --nproc-per-node W ...`), envs
     sharded by rank (global env id = rank*N + i), flat-bucket RCCL gradient all-reduce (ppo.py).
 """
 import os
 import time
-from collections import deque
 
 import torch
 
@@ -34,43 +33,31 @@ def update_linear_schedule(optimizer, epoch, total_num_epochs, initial_lr):
             g["lr"] = lr
 
 
-class EpisodeStats:
-    """Rolling episode statistics (the reference keeps deques of the last 32 finished episodes,
-    train.py:66-70); finished-episode values are gathered on the device, one host copy per log."""
-
-    def __init__(self, maxlen=32):
-        self.reward, self.length, self.success = deque(maxlen=maxlen), deque(maxlen=maxlen), deque(maxlen=maxlen)
-        self.dr = {}
-        self._pending = []
-        self.finished = 0
-
-    def push(self, done, info):
-        self._pending.append((done.bool(), {k: v.clone() for k, v in info.items()}))
-
-    def flush(self, limit=32):
-        for d, info in self._pending:
-            idx = d.nonzero().flatten()
-            self.finished += int(idx.numel())
-            if idx.numel() == 0:
-                continue
-            idx = idx[-limit:]
-            self.reward.extend(info["episode_reward"][idx].tolist())
-            self.length.extend(info["episode_length"][idx].tolist())
-            self.success.extend(info["success"][idx].float().tolist())
-            for k, name in (("dr_stand", "dr/stand_rew"), ("dr_joint_pose", "dr/joint_pose_rew"), ("dr_torque", "dr/torque_rew"),
-                            ("dr_balance", "dr/roll_pitch_balance_rew"), ("dr_progress", "dr/progress_rew")):
-                self.dr.setdefault(name, deque(maxlen=32)).extend(info[k][idx].tolist())
-        self._pending = []
+def episode_stats(envs, device):
+    """Means over ALL episodes finished since the last call (every step counts), from the engine's on-device
+    accumulators (vec_env.SoloVecEnv.episode_stat_sums; include/solorl.h `ep_stats`), summed over ranks.  The
+    reference keeps deques of the last 32 finished episodes (agents/ppo/train.py:66-70,90-100) and prints their
+    mean; with thousands of envs the per-interval mean is the same quantity without the 32-episode window."""
+    from ..config import EPSTAT_NAMES
+    sums = envs.episode_stat_sums(reset=True)
+    if D.world() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    tot = sums.tolist()
+    n = tot[0]
+    out = {"episodes": int(n), "nan_resets": int(tot[9])}
+    for k in range(1, 9):
+        out[EPSTAT_NAMES[k]] = (tot[k] / n) if n > 0 else float("nan")
+    return out
 
 
-def rollout(envs, actor_critic, storage, num_steps, stats=None):
-    """train.py:82-103: T steps of act -> env.step -> storage.append, entirely on the device."""
+def rollout(envs, actor_critic, storage, num_steps):
+    """train.py:82-103: T steps of act -> env.step -> storage.append, entirely on the device (the episode statistics
+    of train.py:90-100 are accumulated by the step kernel itself)."""
     for step in range(num_steps):
         with torch.no_grad():
             value, action, logp = actor_critic.act(storage.obs[step])
         obs, reward, done, info = envs.step_inplace(action.contiguous())
-        if stats is not None and step % 8 == 7:       # sample the episode statistics sparsely
-            stats.push(done, info)
         storage.append(obs, action, logp, value, reward.unsqueeze(-1), (1.0 - done.float()).unsqueeze(-1))
 
 
@@ -94,12 +81,11 @@ def train(args, config, env_constructor=None, writer=None):
     storage = RolloutStorage(args.num_steps, N, envs.observation_space.shape, action_dim, device)
     storage.obs[0].copy_(envs.reset())
     torch.manual_seed(args.seed + 1000 * rank)        # but different action noise per rank
-    stats = EpisodeStats()
     if use_graphs:
         with torch.no_grad():
             actor_critic.act(storage.obs[0]); actor_critic.get_value(storage.obs[0])    # library workspaces before capture
         torch.manual_seed(args.seed + 1000 * rank)
-        graphed_rollout = GraphedRollout(envs, actor_critic, storage, args.num_steps, stats)
+        graphed_rollout = GraphedRollout(envs, actor_critic, storage, args.num_steps)
     start = time.time()
     num_updates = int(args.num_env_steps) // args.num_steps // (N * world)
     history = []
@@ -109,7 +95,7 @@ def train(args, config, env_constructor=None, writer=None):
         if use_graphs:
             graphed_rollout()
         else:
-            rollout(envs, actor_critic, storage, args.num_steps, stats)
+            rollout(envs, actor_critic, storage, args.num_steps)
         with torch.no_grad():
             next_value = actor_critic.get_value(storage.obs[-1])
         storage.compute_returns(next_value, args.use_gae, args.gamma, args.tau)
@@ -124,12 +110,11 @@ def train(args, config, env_constructor=None, writer=None):
             torch.save(ckpt, os.path.join(args.logdir, "solo_{}.pt".format(total)))
             torch.save(ckpt, os.path.join(args.logdir, "solo.pt"))
         if j % args.log_interval == 0:
-            stats.flush()
+            es = episode_stats(envs, device)
             fps = int(total / (time.time() - start))
             rec = dict(update=j, timesteps=total, fps=fps, value_loss=value_loss, action_loss=action_loss, entropy=entropy,
-                       ep_reward=(sum(stats.reward) / len(stats.reward)) if stats.reward else float("nan"),
-                       ep_length=(sum(stats.length) / len(stats.length)) if stats.length else float("nan"),
-                       success=(sum(stats.success) / len(stats.success)) if stats.success else float("nan"))
+                       ep_reward=es["episode_reward"], ep_length=es["episode_length"], success=es["success"],
+                       episodes=es["episodes"], **{k: v for k, v in es.items() if k.startswith("dr/")})
             history.append(rec)
             if rank == 0:
                 print("Updates {update}, num timesteps {timesteps}, FPS {fps}\n mean reward {ep_reward:.2f} mean length "
@@ -138,4 +123,7 @@ def train(args, config, env_constructor=None, writer=None):
                 if writer is not None:
                     for k in ("value_loss", "action_loss", "entropy", "ep_reward", "ep_length", "success"):
                         writer.add_scalar(k, rec[k], total)
+                    for k in rec:
+                        if k.startswith("dr/"):          # agents/ppo/train.py:98-100, utils.log of the dr/ deques
+                            writer.add_scalar(k, rec[k], total)
     return actor_critic, history

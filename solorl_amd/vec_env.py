@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .config import SoloConfig, EnvState, InfoSoA, config_from_dict, TASK_POINTGOAL
+from .config import SoloConfig, EnvState, InfoSoA, config_from_dict, EPSTAT_FIELDS, EPSTAT_NAMES
 
 
 class Box:
@@ -91,6 +91,8 @@ class SoloVecEnv:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         device = torch.device(device) if device is not None else None
+        if device is not None and device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         if device is None or device.type != "cuda":
             raise _native.SoloRLError("SoloVecEnv needs a HIP device (got %r); the engine has no CPU fallback" % (device,))
         self.device = device
@@ -113,7 +115,9 @@ class SoloVecEnv:
         self._info = {k: torch.zeros((N,), dtype=(torch.uint8 if k in ("timeout", "success", "nan_reset") else
                                                    torch.int32 if k == "episode_length" else torch.float32), **kw)
                       for k in _INFO_KEYS}
-        self._info_c = InfoSoA(**{k: self._info[k].data_ptr() for k in _INFO_KEYS})
+        # finished-episode accumulators [fields][N], updated by the step kernel itself (include/solorl.h ep_stats)
+        self._ep_stats = torch.zeros((EPSTAT_FIELDS, N), dtype=torch.float32, **kw)
+        self._info_c = InfoSoA(ep_stats=self._ep_stats.data_ptr(), **{k: self._info[k].data_ptr() for k in _INFO_KEYS})
         self.ob_rms = None          # VecNormalize(ob=False): agents/ppo/envs.py:26, read at train.py:126
         self.closed = False
 
@@ -151,7 +155,12 @@ class SoloVecEnv:
 
     def step_inplace(self, actions):
         """Zero-copy variant for rollout loops: returns views of the engine-owned output buffers
-        (overwritten by the next step)."""
+        (overwritten by the next step).  ``actions`` is handed to the kernel as a raw pointer, so it must already be
+        what the C ABI expects: float32, contiguous, [N, A], on this env's device (host-side checks only, capturable)."""
+        if not (actions.is_cuda and actions.device == self.device and actions.dtype == torch.float32
+                and actions.is_contiguous() and tuple(actions.shape) == (self.nenvs, self.act_dim)):
+            raise AssertionError("step_inplace needs a contiguous float32 [%d, %d] tensor on %s, got %s %s on %s" % (
+                self.nenvs, self.act_dim, self.device, actions.dtype, tuple(actions.shape), actions.device))
         with torch.cuda.device(self.device):
             _native.check(self.L.solorl_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()),
                                              C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
@@ -162,6 +171,27 @@ class SoloVecEnv:
         with torch.cuda.device(self.device):
             _native.check(self.L.solorl_get_observation(self._h, C.c_void_p(self._obs.data_ptr()), self._stream()))
         return self._obs.clone()
+
+    def episode_stat_sums(self, reset=True):
+        """Device tensor [SOLORL_EPSTAT_FIELDS]: the accumulators summed over this handle's envs (all-reduce it across
+        ranks before dividing by field 0)."""
+        tot = self._ep_stats.sum(dim=1)
+        if reset:
+            self._ep_stats.zero_()
+        return tot
+
+    def episode_stats(self, reset=True):
+        """Statistics of the episodes finished since the last call, reduced on the device from the engine's
+        per-env accumulators (every step counts, nothing is sampled): the quantities the reference collects by
+        iterating N info dicts per step (agents/ppo/train.py:90-100) -- means of info['episode_reward'] (the LAST
+        step's reward, baseEnv.py:65), info['episode_length'], info['success'] and the info['dr/*'] sums over the
+        finished episodes -- plus their count.  One small device->host copy; ``reset`` zeroes the accumulators."""
+        tot = self.episode_stat_sums(reset).tolist()
+        n = tot[0]
+        out = {"episodes": int(n), "nan_resets": int(tot[9])}
+        for k in range(1, 9):
+            out[EPSTAT_NAMES[k]] = (tot[k] / n) if n > 0 else float("nan")
+        return out
 
     def increment_curriculum(self, value=1.0):
         _native.check(self.L.solorl_increment_curriculum(self._h, float(value)))

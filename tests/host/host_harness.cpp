@@ -17,8 +17,10 @@ static void run(solorl_env_state* s, const solorl_config* c, int apply_tau) {
   pp.dt = (T)c->sim_dt; pp.gravity = (T)c->gravity; pp.erp = (T)c->erp; pp.slop = (T)c->linear_slop; pp.warm = (T)c->warmstart;
   pp.damping = (T)c->damping; pp.vmax = (T)c->max_velocity; pp.qlim = (T)c->joint_limit; pp.inv_dt = (T)(1.0 / c->sim_dt);
   pp.iterations = c->solver_iterations;
+  pp.tm_on = c->use_treadmill; pp.tm_hw = (T)c->treadmill_half_width; pp.tm_mu = (T)c->treadmill_friction;
   SubCtx<T, ROBOT> C;
   PhysState<T, NQ>& st = C.ps;
+  C.tmy = (T)s->treadmill_y;
   st.pos = mk((T)s->pos[0], (T)s->pos[1], (T)s->pos[2]);
   st.qx = (T)s->quat[0]; st.qy = (T)s->quat[1]; st.qz = (T)s->quat[2]; st.qw = (T)s->quat[3];
   st.v = mk((T)s->lin_vel[0], (T)s->lin_vel[1], (T)s->lin_vel[2]);

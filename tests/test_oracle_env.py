@@ -172,3 +172,52 @@ def test_pd_matches_reference_vectors():
         tau = np.clip(cse["Kp"] * (np.clip(np.array(cse["q_ref"]) / 10, -1, 1) * 10 - np.array(cse["q"])) -
                       cse["Kd"] * np.array(cse["q_dot"]), -3, 3)
         assert np.allclose(tau, cse["tau"], atol=1e-12)
+
+
+# ---------------------------------------------------------------- treadmill (simulation.py:45-77)
+def test_treadmill_side_is_redrawn_at_reset_and_hides_feet_from_the_sensor():
+    c = mk(ROBOT_SOLO12, TASK_WALK, use_treadmill=1, settle_min=8, settle_max=8)
+    o = Oracle(c, 64, seed=5); obs = o.reset()
+    ys = np.array([o.get_state(i).treadmill_y for i in range(64)])
+    assert set(np.round(ys, 6)) == {-0.49, 0.49}                      # 0.49 * choice([-1, 1]), simulation.py:49,72-74
+    assert all(o.get_state(i).rng_counter == 2 for i in range(64))    # two draws per reset: strip side, settle count
+    # all four feet are down after the settle; the strip (1 m wide, centred on +-0.49) lies under the left (y > 0) or
+    # the right feet, and the sensor only sees plane contacts (solo.py:313-317 queries ground_id)
+    for i in range(64):
+        s = o.get_state(i)
+        assert all((s.contact_mask >> (13 + 2 * f)) & 1 for f in range(4))
+        feet = list(obs[i][34:38])                                     # FL FR HL HR
+        assert feet == ([0, 1, 0, 1] if ys[i] > 0 else [1, 0, 1, 0])
+        assert ((s.contact_mask >> 20) & 0xF) == (0b0101 if ys[i] > 0 else 0b1010)
+    # an episode end redraws the side from the env's own stream
+    c2 = mk(ROBOT_SOLO12, TASK_WALK, use_treadmill=1, episode_length=1)
+    o = Oracle(c2, 256, seed=6); o.reset()
+    y0 = np.array([o.get_state(i).treadmill_y for i in range(256)])
+    o.step(np.zeros((256, 12)))
+    y1 = np.array([o.get_state(i).treadmill_y for i in range(256)])
+    assert 0.3 < (y0 != y1).mean() < 0.7
+    # without the key nothing changes: no draw, no strip
+    o = Oracle(mk(ROBOT_SOLO12, TASK_WALK, settle_min=8, settle_max=8), 4); obs = o.reset()
+    assert o.get_state(0).treadmill_y == 0 and o.get_state(0).rng_counter == 1 and list(obs[0][34:38]) == [1, 1, 1, 1]
+
+
+def test_treadmill_strip_friction():
+    """Sliding robot: the tangential momentum lost in one sub-step equals sum(mu_p * lambda_p) over the sliding
+    contacts, with mu = 1 (link 1.0 x plane 1.0) off the strip and 0.5 (x Bullet's default 0.5) on it."""
+    for tm, expect in ((0, [1.0, 1.0, 1.0, 1.0]), (1, [0.5, 1.0, 0.5, 1.0])):
+        c = default_config(ROBOT_SOLO12, TASK_STAND); c.settle_min = c.settle_max = 8; c.use_treadmill = tm
+        o = Oracle(c, 1, seed=1); o.reset()
+        s = o.get_state(0); s.treadmill_y = 0.49 if tm else 0.0
+        s.lin_vel[0] = 3.0                                             # fast enough that every foot keeps sliding in +x
+        o.set_state(0, s)
+        p0 = o.energy_momentum(0)["p"][0]
+        o.substep(0)
+        p1 = o.energy_momentum(0)["p"][0]
+        lam = o.last_lambda(0)
+        feet = [13, 15, 17, 19]
+        assert all(lam[p] > 0 for p in feet)
+        M, _ = o.mass_matrix(0)
+        v, k = 3.0, c.damping
+        damp = M[3, 3] * v * (k + k * v) * c.sim_dt                    # K3: -m v (k + k|v|) on every link, all moving at ~v
+        want = -sum(mu * lam[p] for mu, p in zip(expect, feet)) - damp
+        assert p1 - p0 == pytest.approx(want, rel=0.01), (tm, p1 - p0, want)

@@ -26,7 +26,12 @@ pytestmark = pytest.mark.gpu
 def make(cfg, N, seed=1, off=0):
     from solorl_amd.vec_env import SoloVecEnv
     from oracle.oracle_py import Oracle
-    return SoloVecEnv(cfg, N, device="cuda:0", seed=seed, env_id_offset=off), Oracle(cfg, N, seed=seed, env_id_offset=off)
+    try:
+        threads = min(16, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        threads = 4
+    return (SoloVecEnv(cfg, N, device="cuda:0", seed=seed, env_id_offset=off),
+            Oracle(cfg, N, seed=seed, env_id_offset=off, threads=threads))      # (OpenMP over envs: results do not depend on it)
 
 
 def obs_diff(a, b, D):

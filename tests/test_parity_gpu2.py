@@ -1,0 +1,347 @@
+"""GPU parity tests, second file: the workloads and branches the first round left to the oracle alone.
+
+  * BASELINE config 5 -- configs/basic_contact.yaml as the in-repo PD path (Solo12 walk, PD gains [5, 0.2],
+    episode length 50): resynced vs the oracle, and the full-size properties at 8192 envs/GPU;
+  * the pointgoal goal-reached / bonus / resample branch and pointgoal-timeout-is-failure on the HIP path;
+  * SURVEY.md 8(d)'s parity input verbatim, with the divergence horizon of the fp32 and fp64 engines read against
+    the oracle's own horizon under a 1e-12 perturbation (fixture walk_torque_traj.npz);
+  * fp32 outliers of the resynced comparison are the states the fp64 engine ALSO amplifies (non-convergent PGS);
+  * curriculum under HIP-graph replay;
+  * the treadmill strip (configs/basic.yaml unmodified);
+  * the engine's finished-episode accumulators vs the per-step info tensors and vs the oracle.
+All through the C ABI (ctypes -> libsolorl_hip.so)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from solorl_amd.config import (default_config, config_from_dict, load_yaml, ROBOT_SOLO8, ROBOT_SOLO12, TASK_WALK,
+                               TASK_POINTGOAL, CONTROL_PD, PRECISION_F64, EPSTAT_NAMES)
+from tests.util import GOLDEN
+from tests.golden.make_golden import walk_cfg, walk_action, divergence_horizon
+from tests.test_parity_gpu import make, obs_diff, cfg_for
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def resync(orc, env, N):
+    for i in range(N):
+        orc.set_state(i, env.get_state(i))
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def config5():
+    c = config_from_dict(load_yaml(os.path.join(ROOT, "configs", "basic_contact.yaml")))
+    assert (c.robot, c.task, c.control, c.episode_length, c.num_history_stack) == (ROBOT_SOLO12, TASK_WALK, CONTROL_PD, 50, 1)
+    assert (c.kp, c.kd, c.frame_skip) == (5.0, 0.2, 4)
+    return c
+
+
+def test_config5_pd_path_resynced_vs_oracle(gpu_device):
+    """60 control steps (one episode end at t = 50 included) of a random PD policy on 128 envs, oracle reloaded with
+    the engine's state before every step."""
+    c = config5()
+    N = 128
+    env, orc = make(c, N, seed=5)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(50)
+    dq, drew, dobs, timeouts = [], [], [], 0
+    for t in range(60):
+        resync(orc, env, N)
+        a = rng.uniform(-1, 1, size=(N, 12)).astype(np.float32) * 0.15       # q_ref = 10 a: +-1.5 rad targets
+        obs, rew, done, infos = env.step(torch.from_numpy(a).cuda())
+        oobs, orew, odone, oinfo = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy(); rew = rew.cpu().numpy()[:, 0]
+        assert np.array_equal(done != 0, odone != 0)
+        ti = infos.tensors
+        assert np.array_equal(ti["episode_length"].cpu().numpy(), oinfo["episode_length"])
+        assert np.array_equal(ti["timeout"].cpu().numpy()[done != 0], oinfo["timeout"][odone != 0])
+        timeouts += int(ti["timeout"].cpu().numpy()[done != 0].sum())
+        ok = (done == 0)
+        for i in np.nonzero(ok)[0]:
+            dq.append(np.abs(np.array(env.get_state(i).q) - np.array(orc.get_state(i).q)).max())
+        drew += list(np.abs(rew - orew)[ok]); dobs += list(obs_diff(obs.cpu().numpy(), oobs, c.state_dim)[ok].max(axis=1))
+        if t == 49:
+            assert done.sum() >= 0.9 * N                      # everybody still up times out at exactly episode_length = 50
+            assert obs_diff(obs.cpu().numpy(), oobs, c.state_dim).max() < 2e-3     # post-reset observations
+    dq = np.array(dq)
+    assert timeouts >= 0.9 * N
+    assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 6e-3, (np.median(dq), np.percentile(dq, 90))
+    assert np.median(drew) < 1e-3 and np.median(dobs) < 1e-3
+
+
+def test_config5_full_size_8192_envs(gpu_device):
+    """BASELINE config 5 size: 8192 envs per GPU, 450 steps of a random PD policy.  Episodes never exceed 50 steps,
+    every env is reset at least 9 times (450 / 50), the rollout is bit-reproducible, and a shard created with
+    env_id_offset equals the matching slice of the big batch."""
+    from solorl_amd.vec_env import SoloVecEnv
+    c = config5()
+    N = 8192
+    g = torch.Generator(device="cuda:0"); g.manual_seed(15)
+    acts = (torch.rand((32, N, 12), device="cuda:0", generator=g) * 2 - 1) * 0.3
+    outs = []
+    for rep in range(2):
+        env = SoloVecEnv(c, N, device="cuda:0", seed=4)
+        env.reset()
+        n_done = torch.zeros(N, device="cuda:0"); max_len = 0; tout = 0
+        for t in range(450):
+            o, r, d, info = env.step_inplace(acts[t % 32])
+            n_done += d.float()
+            if d.any():
+                max_len = max(max_len, int(info["episode_length"][d.bool()].max()))
+                tout += int(info["timeout"][d.bool()].sum())
+        assert torch.isfinite(o).all() and info["nan_reset"].sum().item() == 0
+        assert max_len == 50 and int(n_done.min()) >= 9 and tout > 0
+        st = env.episode_stats()
+        assert st["episodes"] == int(n_done.sum()) and st["episode_length"] <= 50.0
+        outs.append((o.clone(), r.clone(), n_done.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    env_a = SoloVecEnv(c, N, device="cuda:0", seed=4)
+    env_b = SoloVecEnv(c, N // 2, device="cuda:0", seed=4, env_id_offset=N // 2)
+    env_a.reset(); env_b.reset()
+    for t in range(60):
+        oa, _, _, _ = env_a.step_inplace(acts[t % 32]); ob, _, _, _ = env_b.step_inplace(acts[t % 32][N // 2:].contiguous())
+    assert torch.equal(oa[N // 2:], ob)
+
+
+# ------------------------------------------------------------------------------------------------ pointgoal branches
+def test_pointgoal_goal_reached_on_the_hip_path(gpu_device):
+    """baseEnv.py:55-57,174-178 + solo.py:269-272: potential < 0.5 => goals_reached += 1, a new goal is drawn, the env
+    reports done + success with reward 0.1 (T - t) and auto-resets -- engine vs oracle from the same injected state."""
+    c = cfg_for(ROBOT_SOLO12, TASK_POINTGOAL)
+    N = 16
+    env, orc = make(c, N, seed=21)
+    env.reset(); orc.reset()
+    z = torch.zeros(N, 12, device="cuda:0")
+    for t in range(3):
+        env.step(z); orc.step(np.zeros((N, 12)))
+    near = [1, 4, 7, 12]
+    for i in near:                                         # goal 0.3 m from the base: inside the 0.5 m radius
+        s = env.get_state(i); s.goal[0] = s.pos[0] + 0.3; s.goal[1] = s.pos[1]
+        s.potential = 0.3
+        env.set_state(i, s)
+    resync(orc, env, N)
+    rng_before = [env.get_state(i).rng_counter for i in range(N)]
+    obs, rew, done, infos = env.step(z)
+    oobs, orew, odone, oinfo = orc.step(np.zeros((N, 12)))
+    done = done.cpu().numpy(); rew = rew.cpu().numpy()[:, 0]
+    assert [int(d) for d in done] == [1 if i in near else 0 for i in range(N)] == [int(d) for d in odone]
+    ti = infos.tensors
+    for i in near:
+        assert infos[i]["success"] is True and infos[i]["timeout"] is False
+        assert rew[i] == pytest.approx(0.1 * (400 - 4), rel=1e-6) and orew[i] == pytest.approx(0.1 * (400 - 4))
+        assert float(ti["goals_reached"][i]) == 1.0 == oinfo["goals_reached"][i]
+        assert int(ti["episode_length"][i]) == 4 == oinfo["episode_length"][i]
+        sg, so = env.get_state(i), orc.get_state(i)
+        # draws: new goal at the goal-reached event (solo.py:272), then the reset's goal + settle count
+        assert sg.rng_counter == so.rng_counter == rng_before[i] + 3
+        assert np.allclose(sg.goal, so.goal, atol=1e-6) and sg.timestep == 0 and sg.goals_reached == 0 == sg.env_goals_reached
+        assert abs(sg.potential - so.potential) < 1e-5
+    for i in set(range(N)) - set(near):
+        assert abs(rew[i] - orew[i]) < 1e-3 and "success" not in infos[i]
+    assert obs_diff(obs.cpu().numpy(), oobs, c.state_dim).max() < 2e-3
+    st = env.episode_stats()
+    assert st["episodes"] == len(near) and st["success"] == 1.0 and st["episode_reward"] == pytest.approx(39.6, rel=1e-5)
+
+
+def test_pointgoal_timeout_is_a_failure(gpu_device):
+    c = cfg_for(ROBOT_SOLO12, TASK_POINTGOAL, episode_length=3)
+    env, orc = make(c, 8, seed=2)
+    env.reset(); orc.reset()
+    z = torch.zeros(8, 12, device="cuda:0")
+    for t in range(3):
+        obs, rew, done, infos = env.step(z); _, orew, odone, oinfo = orc.step(np.zeros((8, 12)))
+    assert done.sum().item() == 8 and odone.sum() == 8
+    assert all(infos[i]["timeout"] is True and infos[i]["success"] is False for i in range(8))      # baseEnv.py:166
+    assert np.abs(rew.cpu().numpy()[:, 0] - orew).max() < 1e-3                                        # no -10, no bonus
+
+
+# ------------------------------------------------------------------------------------------------ 8(d) parity input
+def test_walk_torque_parity_input_divergence_horizon(gpu_device):
+    """SURVEY.md 8(d) parity run verbatim on the HIP engine (see tests/test_host_harness.py for the regime: the robot
+    is on the ground after 20 steps and the fp64 oracle itself, perturbed by 1e-12 rad, leaves the 1e-3 rad band after
+    `oracle_self_horizon` = 61 steps).  Divergence horizon = first control step with max |dq| > 1e-3 rad vs the
+    committed oracle trajectory."""
+    g = np.load(os.path.join(GOLDEN, "walk_torque_traj.npz"))
+    self_h = int(g["oracle_self_horizon"])
+    hor = {}
+    for name, prec in (("f32", 0), ("f64", PRECISION_F64)):
+        c = walk_cfg(); c.precision = prec
+        env, _ = make(c, 4, seed=1)
+        env.reset()
+        dq = []
+        for t in range(120):
+            a = torch.tensor(np.tile(walk_action(t), (4, 1)), dtype=torch.float32, device="cuda:0")
+            env.step(a)
+            dq.append(max(np.abs(np.array(env.get_state(i).q) - g["q"][t]).max() for i in (0, 3)))
+        hor[name] = divergence_horizon(dq)
+        if name == "f64":
+            assert max(dq[:10]) < 1e-6            # (actions cross the boundary as float32: 3e-8 relative)
+        else:
+            assert max(dq[:10]) < 5e-4
+    print("divergence horizons (control steps): oracle self (1e-12 perturbation) %d, engine fp64 %d, engine fp32 %d" % (
+        self_h, hor["f64"], hor["f32"]))
+    assert hor["f64"] >= 40, hor          # fp64 engine with float32 actions: perturbation 3e-8 instead of 1e-12
+    assert hor["f32"] >= 12, hor
+
+
+def test_fp32_outliers_are_states_the_fp64_engine_amplifies_too(gpu_device):
+    """The resynced comparison allows a few large per-step errors because 50 sweeps of box-friction PGS do not converge
+    in some multi-contact states.  Shown here rather than assumed: the fp32 engine, the fp64
+    engine and the oracle all step from the SAME state; wherever fp32 is off by > 1e-3 rad, the fp64 engine -- whose
+    typical error is 1e-11 -- is off by orders of magnitude more than typical as well (rounding at 1e-16 amplified
+    by the same iteration), and in states the fp64 engine does not amplify, fp32 stays within 1e-3 rad."""
+    c32 = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    c64 = cfg_for(ROBOT_SOLO12, TASK_WALK, precision=PRECISION_F64)
+    N = 128
+    env32, orc = make(c32, N, seed=3)
+    env64, _ = make(c64, N, seed=3)
+    env32.reset(); env64.reset(); orc.reset()
+    rng = np.random.default_rng(0)
+    e32, e64, ncs = [], [], []
+    for t in range(40):
+        for i in range(N):
+            s = env32.get_state(i)
+            orc.set_state(i, s); env64.set_state(i, s)
+        a = rng.uniform(-1.2, 1.2, size=(N, 12)).astype(np.float32) * (0.3 if t < 15 else 1.0)
+        ta = torch.from_numpy(a).cuda()
+        _, _, d32, _ = env32.step(ta); _, _, d64, _ = env64.step(ta); _, _, od, _ = orc.step(a.astype(np.float64))
+        d32 = d32.cpu().numpy(); d64 = d64.cpu().numpy()
+        for i in range(N):
+            if d32[i] or d64[i] or od[i]:
+                continue
+            qo = np.array(orc.get_state(i).q)
+            e32.append(np.abs(np.array(env32.get_state(i).q) - qo).max())
+            e64.append(np.abs(np.array(env64.get_state(i).q) - qo).max())
+            ncs.append(bin(orc.get_state(i).contact_mask & 0xFFFFF).count("1"))
+    e32, e64, ncs = np.array(e32), np.array(e64), np.array(ncs)
+    med64 = np.median(e64)
+    out32 = e32 > 1e-3
+    print("samples %d, fp32 outliers %d, median e64 %.1e; e64 at the fp32 outliers: min %.1e median %.1e; contacts there: %s" % (
+        len(e32), out32.sum(), med64, e64[out32].min() if out32.any() else 0, np.median(e64[out32]) if out32.any() else 0,
+        np.bincount(ncs[out32]) if out32.any() else []))
+    assert med64 < 1e-11 and len(e32) > 3000
+    assert out32.sum() < 0.05 * len(e32)
+    # every fp32 outlier is amplified >= 1000x over the typical error in fp64 too
+    assert (e64[out32] > 1e3 * med64).all(), e64[out32].min()
+    # and where fp64 is quiet (within 100x of its typical error) fp32 is inside the north-star tolerance
+    quiet = e64 < 1e2 * med64
+    assert quiet.sum() > 0.5 * len(e32) and (e32[quiet] < 1e-3).all(), e32[quiet].max()
+
+
+# ------------------------------------------------------------------------------------------------ curriculum + graphs
+def test_curriculum_is_seen_by_a_replayed_graph(gpu_device):
+    """solo.py:332-334 / agents/ppo/train.py:116-117 on the default (HIP graph) training path: goal_radius lives in a
+    device block the kernel reads, so a rollout graph captured BEFORE increment_curriculum() samples wider goals when
+    replayed after it."""
+    from solorl_amd.vec_env import SoloVecEnv
+    from solorl_amd.ppo import Policy, RolloutStorage
+    from solorl_amd.ppo.graphs import GraphedRollout
+    c = cfg_for(ROBOT_SOLO12, TASK_POINTGOAL, episode_length=20)
+    N, T = 1024, 25
+    env = SoloVecEnv(c, N, device="cuda:0", seed=3)
+    torch.manual_seed(0)
+    pol = Policy(env.observation_space.shape, env.action_space, None, {"hidden_size": 32}).to("cuda:0")
+    st = RolloutStorage(T, N, env.observation_space.shape, env.act_dim, torch.device("cuda:0"))
+    st.obs[0].copy_(env.reset())
+    with torch.no_grad():
+        pol.act(st.obs[0])
+    roll = GraphedRollout(env, pol, st, T)
+    roll()                                                 # captures + replays once: every env resets (T > episode_length)
+    torch.cuda.synchronize()
+    assert roll.graph is not None
+    goal = st.obs[-1][:, 40:42] * 2
+    assert (goal.abs() < 2.0).all() and (goal.abs() >= 1.0).all()
+    env.increment_curriculum()                             # radius 2 -> 3
+    st.reset(); roll()
+    torch.cuda.synchronize()
+    goal = st.obs[-1][:, 40:42] * 2
+    assert (goal.abs() < 3.0).all() and (goal.abs() >= 2.0).any(), float(goal.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ treadmill
+def test_treadmill_configs_basic_yaml_vs_oracle(gpu_device):
+    """configs/basic.yaml unmodified (Solo8 walk, use_treadmill: True): reset (strip side from the env's Philox stream,
+    snapshot per side), 40 resynced control steps, feet flags of the observation hidden on the strip."""
+    c = config_from_dict(load_yaml(os.path.join(ROOT, "configs", "basic.yaml")))
+    assert c.use_treadmill == 1 and c.robot == ROBOT_SOLO8 and c.task == TASK_WALK
+    N = 128
+    env, orc = make(c, N, seed=13)
+    og = env.reset().cpu().numpy().astype(np.float64); oo = orc.reset()
+    assert obs_diff(og, oo, c.state_dim).max() < 2e-3
+    ys = np.array([env.get_state(i).treadmill_y for i in range(N)])
+    assert np.allclose(ys, [orc.get_state(i).treadmill_y for i in range(N)], atol=1e-6) and set(np.round(ys, 4)) == {-0.49, 0.49}
+    for i in range(N):
+        assert env.get_state(i).contact_mask == orc.get_state(i).contact_mask and env.get_state(i).rng_counter == orc.get_state(i).rng_counter == 2
+    feet = og[:, 26:30]                                     # Solo8: 10 + 2*8 = 26 .. 29: FL FR HL HR
+    assert np.array_equal(feet[ys > 0], np.tile([0, 1, 0, 1], ((ys > 0).sum(), 1)))
+    assert np.array_equal(feet[ys < 0], np.tile([1, 0, 1, 0], ((ys < 0).sum(), 1)))
+    rng = np.random.default_rng(3)
+    dq, mism, strip_seen = [], 0, 0
+    for t in range(40):
+        resync(orc, env, N)
+        a = rng.uniform(-1, 1, size=(N, 8)).astype(np.float32) * (0.3 if t < 20 else 1.0)
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        oobs, orew, odone, _ = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy()
+        for i in range(N):
+            if done[i] or odone[i]:
+                continue
+            sg, so = env.get_state(i), orc.get_state(i)
+            dq.append(np.abs(np.array(sg.q)[:8] - np.array(so.q)[:8]).max())
+            mism += sg.contact_mask != so.contact_mask
+            strip_seen += (sg.contact_mask >> 20) != 0
+    dq = np.array(dq)
+    assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 1e-3, (np.median(dq), np.percentile(dq, 90))
+    assert mism <= 0.02 * len(dq) and strip_seen > 0.3 * len(dq)
+    # the strip matters: the same rollout without it separates from this one
+    c0 = c.copy(); c0.use_treadmill = 0
+    env0, _ = make(c0, N, seed=13)
+    env0.reset()
+    envt, _ = make(c, N, seed=13)
+    envt.reset()
+    a = torch.zeros(N, 8, device="cuda:0"); a[:, 0::2] = 0.5
+    for t in range(30):
+        o0, _, _, _ = env0.step(a); ot, _, _, _ = envt.step(a)
+    assert (o0[:, :10] - ot[:, :10]).abs().max().item() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ episode statistics
+def test_episode_stat_accumulators(gpu_device):
+    """finished-episode statistics reduced on the device over EVERY step.  (1) The engine's accumulators
+    equal, exactly, the same sums formed from its per-step info tensors; (2) over a 450-step unsynchronised rollout
+    they agree with the oracle's per-env infos within sampling noise."""
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK, episode_length=100)
+    N, T = 512, 450
+    env, orc = make(c, N, seed=31)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(32, N, 12)).astype(np.float32)
+    keys = ("episode_reward", "episode_length", "success", "dr_stand", "dr_joint_pose", "dr_torque", "dr_balance", "dr_progress")
+    acc = torch.zeros(9, N, device="cuda:0")
+    oacc = np.zeros(9)
+    for t in range(T):
+        obs, rew, done, infos = env.step(torch.from_numpy(acts[t % 32]).cuda())
+        ti = infos.tensors
+        d = done.bool()
+        acc[0] += d.float()
+        for k, name in enumerate(keys):
+            acc[1 + k] += torch.where(d, ti[name].float(), torch.zeros_like(acc[0]))
+        _, orew, odone, oinfo = orc.step(acts[t % 32].astype(np.float64))
+        od = odone != 0
+        oacc[0] += od.sum(); oacc[1] += oinfo["episode_reward"][od].sum(); oacc[2] += oinfo["episode_length"][od].sum()
+        oacc[3] += oinfo["success"][od].sum(); oacc[4:9] += oinfo["dr"][od].sum(axis=0)
+    raw = env._ep_stats.clone()
+    assert torch.equal(raw[:9], acc) and raw[9].sum().item() == 0
+    st = env.episode_stats()
+    assert env._ep_stats.abs().sum().item() == 0                                  # zeroed by the read
+    n = acc[0].sum().item()
+    assert st["episodes"] == int(n) and n > 2000
+    assert st["episode_length"] == pytest.approx(acc[2].sum().item() / n, rel=1e-5)
+    names = EPSTAT_NAMES[1:9]
+    assert abs(n - oacc[0]) < 0.05 * oacc[0], (n, oacc[0])
+    for k, name in enumerate(names):
+        mine, theirs = st[name], oacc[1 + k] / oacc[0]
+        assert abs(mine - theirs) < 0.1 * abs(theirs) + 0.05, (name, mine, theirs)

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def get_ppo_args(argv=None):
     p = argparse.ArgumentParser("PPO args")
     p.add_argument("--num-agents", type=int, default=32)          # envs PER GPU
+    p.add_argument("--output-size", type=int, default=64)         # accepted and unused, as in the reference (train_ppo.py:12)
     p.add_argument("--hidden-size", type=int, default=64)
     p.add_argument("--no-cuda", action="store_true", default=False)
     p.add_argument("--no-hip-graphs", action="store_true", default=False, help="run rollout and update eagerly instead of replaying HIP graphs")
@@ -27,6 +28,8 @@ def get_ppo_args(argv=None):
     p.add_argument("--value-loss-coef", type=float, default=0.5)
     p.add_argument("--entropy-coef", type=float, default=0.01)
     p.add_argument("--max-grad-norm", type=float, default=0.5)
+    p.add_argument("--clip-value-loss", action="store_true", default=False)   # accepted; the reference's PPO always clips the value
+                                                                               # loss (ppo.py:18 default, the flag is never forwarded)
     p.add_argument("--use-linear-lr-decay", action="store_true", default=False)
     p.add_argument("--use-gae", action="store_true", default=False)
     p.add_argument("--num-env-steps", type=float, default=1e6)
@@ -35,6 +38,7 @@ def get_ppo_args(argv=None):
     p.add_argument("--log-interval", type=int, default=10)
     p.add_argument("--logdir", type=str, default=None)
     p.add_argument("--base-checkpoint", type=str, default=None)
+    p.add_argument("--timestamp", type=str, default=None)
     p.add_argument("--save-interval", type=int, default=20)
     p.add_argument("--config-file", type=str, default="configs/basic.yaml")
     p.add_argument("--task", type=str, default=None)
@@ -56,7 +60,18 @@ def main(argv=None):
         raise SystemExit("the rollout engine is GPU-only (no CPU fallback)")
     if args.num_steps is None:
         args.num_steps = config["episode_length"]
-    train(args, config)
+    writer = None
+    if args.logdir is not None:      # run directory named as training/train_ppo.py:64-72
+        from datetime import datetime
+        stamp = datetime.now().strftime("%Y%m%d-%H%M%S") if args.timestamp is None else datetime.now().strftime("%Y%m%d-") + args.timestamp
+        task = args.task + "_" if args.task is not None else ""
+        args.logdir = os.path.join(args.logdir, "Solo" + args.env_name.capitalize() + "_" + task + stamp)
+        try:                         # tensorboard is optional here (not installed in the build image)
+            from torch.utils.tensorboard import SummaryWriter
+            writer = SummaryWriter(args.logdir)
+        except Exception:
+            writer = None
+    return train(args, config, None, writer)
 
 
 if __name__ == "__main__":
