@@ -90,11 +90,11 @@ class Oracle:
 
     def get_state(self, i=0):
         s = EnvState()
-        self.L.oracle_get_state(self.h, i, C.byref(s))
+        self.L.oracle_get_state(self.h, int(i), C.byref(s))
         return s
 
     def set_state(self, i, s):
-        self.L.oracle_set_state(self.h, i, C.byref(s))
+        self.L.oracle_set_state(self.h, int(i), C.byref(s))
 
     def substep(self, i=0):
         self.L.oracle_substep(self.h, i)

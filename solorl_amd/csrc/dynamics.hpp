@@ -990,35 +990,41 @@ SNI void phase_integrate(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned ns
 // base solve on the team leader (lane 0 of the row); rows are finished by all 16 lanes and swept by
 // pgs_team_variant, where each 8-lane half holds the 18 accumulator components [w(6), y_leg0..3 (12)].
 
-// Team-sweep row storage (after the RowLds<T,4> region).  Rows sit at STATIC positions, two per slot:
+// Team-sweep rows.  The sweep works on STATIC positions, two per slot:
 //   slot 0        positions 0,1           the (<= 2) joint-limit rows
 //   slots 1..4    positions 2+k           normal row of contact k (k = rank of its primitive among the contacts)
 //   slots 5..12   positions 10+2k, 11+2k  the two friction rows of contact k
-// which keeps the solver order [limits | normals | friction pairs] (unused positions inside a swept slot are
-// null rows) and makes the parent of friction slot 5+k a compile-time register: the impulse of slot 1+k/2,
-// half k&1.  Friction rows are stored in units of their contact's mu (lambda~ = lambda/mu, J' = J/mu,
-// B~ = mu B) and every row is pre-scaled by 1/diag, so the sweep needs neither mu nor 1/diag:
-//   rec  [TR][4][38]   18 (J'_c, B~_c) pairs, one per accumulator component c (zero for the components of
-//                      other legs, so no masks in the loop) + 1 zero pair
-//   sca  [TR][4]       rhs'
-//   lam  [TR][4]       impulses (warm start in, result out)
+// which keeps the solver order [limits | normals | friction pairs] and makes the parent of friction slot 5+k a
+// compile-time register: the impulse of slot 1+k/2, half k&1.  A team with fewer rows than its wavefront sweeps
+// null rows at the unused positions (all-zero, decided by the sweep's set-up from the team's row counts).
+// The finished rows stay where they were parked (RowLds core, dense solver index r <-> position by pos_of /
+// row_of), rewritten IN PLACE by phase_finish_team as the 20-value record the sweep needs:
+//   [0..5] J'_base  [6..8] J'_leg  [9..14] B~_base  [15..17] B~_leg  [18] rhs'  [19] leg id
+// Friction rows are stored in units of their contact's mu (lambda~ = lambda/mu, J' = J/mu, B~ = mu B) and every row
+// is pre-scaled by 1/diag, so the sweep needs neither mu nor 1/diag.  (Round 1 expanded every row into a separate
+// 38-value record with explicit zeros for the other legs' components: 15.8 KB of the 34.6 KB per workgroup, which
+// held the kernel at one wavefront per SIMD; now 18.4 KB -> 8 workgroups per CU, two wavefronts per SIMD.)
+//   lam  [TR][4]       impulses by position (warm start in, result out)
+//   bc   [4][BC]       base-solve broadcast block (Lam 36, u*_base 6, leg rates 12, a0 6)
+enum { E_JB = 0, E_JL = 6, E_BB = 9, E_BL = 15, E_RHS = 18, E_LEG = 19 };
 template <typename T, typename LDS> struct TeamRows {
   static_assert(MAX_LIMITS == 2 && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
   static constexpr int NPOS0 = 2, FPOS0 = NPOS0 + MAX_CONTACTS;              // first normal / friction position
   static constexpr int NSLOT = 1 + MAX_CONTACTS / 2 + MAX_CONTACTS;          // 13
-  static constexpr int TR = 2 * NSLOT, REC = 38, SCA = 1, BC = 60;
-  static constexpr size_t off_rec = LDS::bytes(4);
-  static constexpr size_t off_sca = off_rec + (size_t)TR * 4 * REC * sizeof(T);
-  static constexpr size_t off_lam = off_sca + (size_t)TR * 4 * SCA * sizeof(T);
+  static constexpr int TR = 2 * NSLOT, BC = 60;
+  static constexpr size_t off_lam = LDS::bytes(4);
   static constexpr size_t off_bc = off_lam + (size_t)TR * 4 * sizeof(T);
   static constexpr size_t off_ctx = (off_bc + (size_t)4 * BC * sizeof(T) + 15) & ~(size_t)15;   // 4 x SubCtx (size added by the user)
   static constexpr size_t bytes = off_ctx;
-  SD static T* rec(int col) { return reinterpret_cast<T*>(solo_smem + off_rec) + col * REC; }      // + pos*4*REC
-  SD static T* sca(int col) { return reinterpret_cast<T*>(solo_smem + off_sca) + col * SCA; }      // + pos*4*SCA
   SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + pos*4
   SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12, a0 6
   SD static int pos_of(int r, int nlt, int nc) {   // solver row index -> position
     return r < nlt ? r : (r < nlt + nc ? NPOS0 + (r - nlt) : FPOS0 + (r - nlt - nc));
+  }
+  // position -> solver row index, or -1 where the team has no row (null row)
+  SD static int row_of(int pos, int nlt, int nc) {
+    const int kn = pos - NPOS0, kf = pos - FPOS0;
+    return pos < NPOS0 ? (pos < nlt ? pos : -1) : (pos < FPOS0 ? (kn < nc ? nlt + kn : -1) : (kf < 2 * nc ? nlt + nc + kf : -1));
   }
 };
 
@@ -1221,7 +1227,8 @@ template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt
   ncmax = m & 255; anylim = m >> 8;
 }
 
-// all 16 lanes: lane t finishes rows t, t+16 and writes them as team records (layout: TeamRows)
+// all 16 lanes: lane t finishes rows t, t+16 IN PLACE (record layout: TeamRows) and publishes their warm-start impulses
+// by position.  A lane only overwrites the rows it read itself, so no ordering between lanes is needed.
 template <typename T, int ROBOT, typename LDS>
 SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) {
   using TRW = TeamRows<T, LDS>;
@@ -1229,21 +1236,11 @@ SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) 
   int nlt, nc, ncmax, anylim;
   team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
   const int nrows = nlt + 3 * nc, rfric = nlt + nc;
-  T* const rec = TRW::rec(col); T* const sca = TRW::sca(col); T* const lam = TRW::lam(col);
+  T* const lam = TRW::lam(col);
   const T* bc = TRW::bc(col);
-  // null rows: unused positions of the slots the wave will sweep
-  const int nce = (ncmax + 1) & ~1;
-  for (int pos = t; pos < TRW::TR; pos += 16) {
-    const int kn = pos - TRW::NPOS0, kf = pos - TRW::FPOS0;
-    const bool z = pos < TRW::NPOS0 ? (anylim && pos >= nlt) : (pos < TRW::FPOS0 ? (kn >= nc && kn < nce) : (kf >= 2 * nc && kf < 2 * ncmax));
-    if (z) {
-      T* q = rec + pos * (4 * TRW::REC); T* sc = sca + pos * (4 * TRW::SCA);
-#pragma unroll
-      for (int k = 0; k < TRW::REC; k++) q[k] = T(0);
-      sc[0] = T(0);
-      lam[pos * 4] = T(0);
-    }
-  }
+  // impulses of the positions this team leaves empty (the wave may sweep them as null rows)
+  for (int pos = t; pos < TRW::TR; pos += 16)
+    if (TRW::row_of(pos, nlt, nc) < 0) lam[pos * 4] = T(0);
   if (t >= nrows) return;
   Sym6<T> Lam;
 #pragma unroll
@@ -1267,19 +1264,17 @@ SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) 
     SV<T> W; T rhs, dinv;
     finish_row(c, meta, Lam, ub, ql[0], ql[1], ql[2], pp, W, rhs, dinv);
     const bool fr = r >= rfric;
-    const int pos = TRW::pos_of(r, nlt, nc);
     const T sB = fr ? mu : T(1);
     const T sJ = dinv / sB;
-    T* q = rec + pos * (4 * TRW::REC);
-    T* sc = sca + pos * (4 * TRW::SCA);
-    q[0] = c[0] * sJ; q[1] = W.a.x * sB; q[2] = c[1] * sJ; q[3] = W.a.y * sB; q[4] = c[2] * sJ; q[5] = W.a.z * sB;
-    q[6] = c[3] * sJ; q[7] = W.l.x * sB; q[8] = c[4] * sJ; q[9] = W.l.y * sB; q[10] = c[5] * sJ; q[11] = W.l.z * sB;
-#pragma unroll
-    for (int k = 12; k < TRW::REC; k++) q[k] = T(0);
-    T* ql2 = q + 12 + 6 * leg;
-    ql2[0] = c[6] * sJ; ql2[1] = c[15] * sB; ql2[2] = c[7] * sJ; ql2[3] = c[16] * sB; ql2[4] = c[8] * sJ; ql2[5] = c[17] * sB;
-    sc[0] = rhs / sB;                   // finish_row's rhs already carries 1/diag
-    lam[pos * 4] = c[13];               // warm-start impulse (0 for friction / limit rows)
+    T o[ROW_CORE];
+    o[E_JB + 0] = c[0] * sJ; o[E_JB + 1] = c[1] * sJ; o[E_JB + 2] = c[2] * sJ; o[E_JB + 3] = c[3] * sJ; o[E_JB + 4] = c[4] * sJ; o[E_JB + 5] = c[5] * sJ;
+    o[E_JL + 0] = c[6] * sJ; o[E_JL + 1] = c[7] * sJ; o[E_JL + 2] = c[8] * sJ;
+    o[E_BB + 0] = W.a.x * sB; o[E_BB + 1] = W.a.y * sB; o[E_BB + 2] = W.a.z * sB; o[E_BB + 3] = W.l.x * sB; o[E_BB + 4] = W.l.y * sB; o[E_BB + 5] = W.l.z * sB;
+    o[E_BL + 0] = c[15] * sB; o[E_BL + 1] = c[16] * sB; o[E_BL + 2] = c[17] * sB;
+    o[E_RHS] = rhs / sB;                // finish_row's rhs already carries 1/diag
+    o[E_LEG] = T(leg);
+    lds.store_core(r, o);
+    lam[TRW::pos_of(r, nlt, nc) * 4] = c[13];      // warm-start impulse (0 for friction / limit rows)
   };
   emit(t, c0, meta0, mu0);
   if (two) emit(r1, c1, meta1, mu1);
@@ -1331,18 +1326,23 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   struct Ord { static constexpr int slot(int i) { return i < LIM ? 0 : (i < LIM + NNS ? S_N0 + (i - LIM) : S_F0 + (i - LIM - NNS)); } };
   const int col = lds.lane;
   const int h = t & 7, half = t >> 3;
-  const int cc = h < 2 ? 16 + h : 18;           // third accumulator component (or the zero pair)
   constexpr int SZ = (int)sizeof(T);
-  constexpr int S_REC = 4 * TRW::REC * SZ, S_SCA = 4 * TRW::SCA * SZ, S_LAM = 4 * SZ;
-  constexpr int dB = 2 * 8 * SZ;
-  const int dC = 2 * (cc - h) * SZ;
-  using P2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
-  auto ldT = [&](int off) -> T { return *reinterpret_cast<const T*>(solo_smem + off); };
-  auto ld2 = [&](int off) -> P2 { return *reinterpret_cast<const P2*>(solo_smem + off); };
-  const int rec_own = (int)TRW::off_rec + (col * TRW::REC + 2 * h) * SZ + half * S_REC;
-  const int rec_oth = rec_own + (1 - 2 * half) * S_REC;
-  const int sca_own = (int)TRW::off_sca + col * TRW::SCA * SZ + half * S_SCA;
+  constexpr int S_LAM = 4 * SZ;
   const int lam_own = (int)TRW::off_lam + col * SZ + half * S_LAM;
+  // this team's row counts: position -> parked row (TeamRows::row_of), or a null row
+  const int nlt = (int)lds.hdr()[0], nc = (int)lds.hdr()[LN];
+  // Lane h of a half holds accumulator components h, h + 8 and (h < 2) 16 + h of [w(6), y_leg0..3(12)].  Where they
+  // sit in a finished record (TeamRows): component c < 6 -> base element c; c >= 6 -> leg (c-6)/3, joint (c-6)%3,
+  // present only in rows of that leg.
+  const int eU = h;                                   // comp h: base 0..5 | leg 0 joints 0,1 (J' at E_JL = 6: same index)
+  const int legU = h < 6 ? -1 : 0;                    // -1: every row
+  const int eV = E_JL + (h + 2) % 3, legV = (h + 2) / 3;
+  const int eW = E_JL + 1 + h, legW = h < 2 ? 3 : -2; // -2: no row (the zero pair)
+  constexpr int dJB = E_BB - E_JB;                    // J' element -> B~ element (base: +9, leg: +9 as well)
+  static_assert(E_BL - E_JL == dJB, "record layout");
+  auto elem = [&](int r, int e) -> T {                // element e of parked row r
+    return *reinterpret_cast<const T*>(solo_smem + ((unsigned)((r * LDS::NCH + e / LDS::PER) * LN + col) * 16u + (unsigned)(e % LDS::PER) * SZ));
+  };
   // all arrays below are indexed by the sweep index i
   T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
   T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
@@ -1350,19 +1350,26 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   static_for<n>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int k = Ord::slot(i);
-    const P2 u = ld2(rec_own + 2 * k * S_REC), v = ld2(rec_own + 2 * k * S_REC + dB), w = ld2(rec_own + 2 * k * S_REC + dC);
-    J0[i] = u.x; B0[i] = u.y; J1[i] = v.x; B1[i] = v.y; J2[i] = w.x; B2[i] = w.y;
-    X0[i] = ldT(rec_oth + 2 * k * S_REC + SZ); X1[i] = ldT(rec_oth + 2 * k * S_REC + dB + SZ); X2[i] = ldT(rec_oth + 2 * k * S_REC + dC + SZ);
-    rh[i] = ldT(sca_own + 2 * k * S_SCA);
+    const int r_own = TRW::row_of(2 * k + half, nlt, nc), r_oth = TRW::row_of(2 * k + 1 - half, nlt, nc);
+    const int ro = r_own < 0 ? 0 : r_own, rx = r_oth < 0 ? 0 : r_oth;        // (a safe row to read; the value is discarded)
+    const int lo = r_own < 0 ? -3 : (int)elem(ro, E_LEG), lx = r_oth < 0 ? -3 : (int)elem(rx, E_LEG);
+    const bool uo = r_own >= 0 && (legU == -1 || legU == lo), vo = legV == lo, wo = legW == lo;
+    const bool ux = r_oth >= 0 && (legU == -1 || legU == lx), vx = legV == lx, wx = legW == lx;
+    const T ju = elem(ro, eU), bu = elem(ro, eU + dJB), jv = elem(ro, eV), bv = elem(ro, eV + dJB), jw = elem(ro, eW), bw = elem(ro, eW + dJB);
+    const T xu = elem(rx, eU + dJB), xv = elem(rx, eV + dJB), xw = elem(rx, eW + dJB);
+    const T rhs = elem(ro, E_RHS);
+    J0[i] = uo ? ju : T(0); B0[i] = uo ? bu : T(0); J1[i] = vo ? jv : T(0); B1[i] = vo ? bv : T(0); J2[i] = wo ? jw : T(0); B2[i] = wo ? bw : T(0);
+    X0[i] = ux ? xu : T(0); X1[i] = vx ? xv : T(0); X2[i] = wx ? xw : T(0);
+    rh[i] = r_own >= 0 ? rhs : T(0);
     // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
     // partner's B~; half 0 takes 0 (its row does not wait for anybody)
     const T c = team_red8(J0[i] * X0[i] + J1[i] * X1[i] + J2[i] * X2[i]);
     cp[i] = half ? c : T(0);
-    lm[i] = ldT(lam_own + 2 * k * S_LAM);
+    lm[i] = *reinterpret_cast<const T*>(solo_smem + lam_own + 2 * k * S_LAM);
     // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
-    const T lx = half_swap(lm[i]);
-    if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx;
-    a0 += B0[i] * lm[i] + X0[i] * lx; a1 += B1[i] * lm[i] + X1[i] * lx; a2 += B2[i] * lm[i] + X2[i] * lx;
+    const T lx_ = half_swap(lm[i]);
+    if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx_;
+    a0 += B0[i] * lm[i] + X0[i] * lx_; a1 += B1[i] * lm[i] + X1[i] * lx_; a2 += B2[i] * lm[i] + X2[i] * lx_;
   });
   // couplings with the predecessor slot (wrapping around: the first slot follows the last one of the previous sweep)
   static_for<n>([&](auto ic) {

