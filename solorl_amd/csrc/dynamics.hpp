@@ -34,10 +34,23 @@ constexpr int NPRIM = 20;
 constexpr double LIMIT_WINDOW = 0.5;
 constexpr double DISC_EPS2 = 1e-12;
 
+// dev builds (-DSOLO_WAVE_TIMING, tools/dev/wave_hist.py): four time stamps per wavefront, kept in registers and written with
+// plain stores at the very end (no atomics, nothing on the sub-steps' path): [workgroup][0] kernel start -> first sub-step,
+// [1] the sub-steps, [2] last sub-step -> end, [3] whole kernel in s_memrealtime ticks (100 MHz), [4] sum over the sub-steps of
+// the slots the wave swept, [5] the maximum over the sub-steps of its largest contact count
+#if defined(SOLO_WAVE_TIMING) && !defined(SOLO_HOST_SHIM)
+constexpr int SOLO_WT_WAVES = 65536, SOLO_WT_FIELDS = 6;
+__device__ unsigned long long solo_wave_times[SOLO_WT_WAVES][SOLO_WT_FIELDS];
+#endif
 // dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
 #if defined(SOLO_PHASE_TIMING) && !defined(SOLO_HOST_SHIM)
 __device__ unsigned long long solo_phase_cycles[48];
-#define SOLO_TICK(i) do { const long long now_ = clock64(); if (threadIdx.x == 0) atomicAdd(&solo_phase_cycles[i], (unsigned long long)(now_ - tick_)); tick_ = clock64(); } while (0)
+// per-wavefront records of ONE launch (tools/dev/wave_hist.py zeroes them before it): [workgroup][0..6] cycles per phase
+// (index as solo_phase_cycles), [8] whole kernel, [9] sum over the sub-steps of the wave's largest contact count, [10] its maximum
+constexpr int SOLO_WREC_WAVES = 16384, SOLO_WREC_FIELDS = 12;
+__device__ unsigned long long solo_wave_rec[SOLO_WREC_WAVES][SOLO_WREC_FIELDS];
+#define SOLO_TICK(i) do { const long long now_ = clock64(); if (threadIdx.x == 0) { atomicAdd(&solo_phase_cycles[i], (unsigned long long)(now_ - tick_)); \
+    if (blockIdx.x < SOLO_WREC_WAVES) solo_wave_rec[blockIdx.x][i] += (unsigned long long)(now_ - tick_); } tick_ = clock64(); } while (0)
 #define SOLO_TICK_INIT long long tick_ = clock64()
 #else
 #define SOLO_TICK(i) do {} while (0)
@@ -1443,6 +1456,12 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
 #ifdef SOLO_PHASE_TIMING
   const long long pgs_t0_ = clock64();
 #endif
+#if defined(SOLO_WAVE_TIMING)
+  if (threadIdx.x == 0 && blockIdx.x < SOLO_WT_WAVES) {
+    solo_wave_times[blockIdx.x][4] += (unsigned long long)(ncmax + (ncmax + 1) / 2 + (anylim ? 1 : 0));   // slots swept
+    if ((unsigned long long)ncmax > solo_wave_times[blockIdx.x][5]) solo_wave_times[blockIdx.x][5] = (unsigned long long)ncmax;
+  }
+#endif
 #define SOLO_SWEEP_L(N_, F_) do { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_>(iterations, lds, t); \
                                   else pgs_team_variant<T, LDS, 0, N_, F_>(iterations, lds, t); } while (0)
   switch (ncmax) {       // wave-uniform
@@ -1472,6 +1491,10 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
   if (threadIdx.x == 0) {
     atomicAdd(&solo_pgs_cycles[0][ncmax], (unsigned long long)(clock64() - pgs_t0_));
     atomicAdd(&solo_pgs_cycles[1][ncmax], 1ull);
+    if (blockIdx.x < SOLO_WREC_WAVES) {
+      solo_wave_rec[blockIdx.x][9] += (unsigned long long)ncmax;
+      if ((unsigned long long)ncmax > solo_wave_rec[blockIdx.x][10]) solo_wave_rec[blockIdx.x][10] = (unsigned long long)ncmax;
+    }
   }
 #endif
 }

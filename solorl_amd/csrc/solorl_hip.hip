@@ -266,6 +266,10 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #ifdef SOLO_PHASE_TIMING
   const long long kstart_ = clock64();
 #endif
+#ifdef SOLO_WAVE_TIMING
+  const long long wt0_ = clock64(), wr0_ = wall_clock64();
+  long long wt1_ = 0, wt2_ = 0;
+#endif
   const int t = TEAM ? (threadIdx.x & 15) : 0;
   const int col = TEAM ? (threadIdx.x >> 4) : threadIdx.x;
   // team mode: a workgroup touches only 16 B of each state field, so eight consecutive workgroups share every
@@ -359,6 +363,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #ifdef SOLO_PHASE_TIMING
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
 #endif
+#ifdef SOLO_WAVE_TIMING
+    wt1_ = clock64();
+#endif
     if (lead) { ch.get().ps = E.ps; ch.get().tmy = E.tmy; }
     TEAM_SYNC();
     // warm-start impulse cache: HBM -> LDS once per step (a global load/store per sub-step left a memory round
@@ -374,6 +381,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const int m = substep_team<T, ROBOT>(pp, sf + (idx_t)L.lam * N + e, (idx_t)N, lds, t, lead, valid);
       if (lead) E.mask = m;
     }
+#ifdef SOLO_WAVE_TIMING
+    wt2_ = clock64();
+#endif
     if (lead) E.ps = ch.get().ps;
     if (valid) for (int p = t; p < NPRIM; p += 16) sf[(idx_t)(L.lam + p) * N + e] = ch.get().lamp[p];
 #ifdef SOLO_PHASE_TIMING
@@ -506,6 +516,18 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
         }
       }
     }
+#ifdef SOLO_PHASE_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < solo::SOLO_WREC_WAVES) solo::solo_wave_rec[blockIdx.x][8] = (unsigned long long)(clock64() - kstart_);
+#endif
+#ifdef SOLO_WAVE_TIMING
+    __builtin_amdgcn_s_waitcnt(0);     // (vmcnt = lgkmcnt = 0: the stores above have left)
+    if (threadIdx.x == 0 && blockIdx.x < solo::SOLO_WT_WAVES) {
+      const long long wt3_ = clock64();
+      unsigned long long* w_ = solo::solo_wave_times[blockIdx.x];
+      w_[0] = (unsigned long long)(wt1_ - wt0_); w_[1] = (unsigned long long)(wt2_ - wt1_); w_[2] = (unsigned long long)(wt3_ - wt2_);
+      w_[3] = (unsigned long long)(wall_clock64() - wr0_);
+    }
+#endif
   }
 }
 
@@ -864,6 +886,31 @@ int solorl_debug_phase_cycles(unsigned long long* out16, int reset) {   // (48 v
   if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_phase_cycles), z, sizeof(z)) != hipSuccess) return -3; }
   return 0;
 }
+int solorl_debug_wave_records(unsigned long long* out, int nwaves, int reset) {    // [nwaves][SOLO_WREC_FIELDS]
+  if (nwaves > solo::SOLO_WREC_WAVES) nwaves = solo::SOLO_WREC_WAVES;
+  const size_t bytes = (size_t)nwaves * solo::SOLO_WREC_FIELDS * sizeof(unsigned long long);
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(solo::solo_wave_rec), bytes) != hipSuccess) return -3;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(solo::solo_wave_rec)) != hipSuccess || hipMemset(p, 0, sizeof(solo::solo_wave_rec)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif
+#ifdef SOLO_WAVE_TIMING
+extern "C" int solorl_debug_wave_times(unsigned long long* out, int nwaves, int reset) {    // [nwaves][SOLO_WT_FIELDS]
+  if (nwaves > solo::SOLO_WT_WAVES) nwaves = solo::SOLO_WT_WAVES;
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(solo::solo_wave_times), (size_t)nwaves * solo::SOLO_WT_FIELDS * sizeof(unsigned long long)) != hipSuccess) return -3;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(solo::solo_wave_times)) != hipSuccess || hipMemset(p, 0, sizeof(solo::solo_wave_times)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif
+#ifdef SOLO_PHASE_TIMING
 int solorl_debug_pgs_cycles(unsigned long long* out20, int reset) {
   if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(solo::solo_pgs_cycles), 20 * sizeof(unsigned long long)) != hipSuccess) return -3;
   if (reset) { unsigned long long z[20] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_pgs_cycles), z, sizeof(z)) != hipSuccess) return -3; }
