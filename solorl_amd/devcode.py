@@ -39,6 +39,42 @@ def function_stats(lib_path):
     return out
 
 
+def loop_stats(lib_path, name_filter):
+    """For every function whose mangled name contains `name_filter`: the outermost backward branch spanning more than
+    200 bytes is taken as THE loop; returns {name: {"insts", "scratch", "scratch_in_loop", "valu_in_loop", "lds_in_loop"}}.
+    Used to pin that the PGS sweep loops touch no memory at all (callee-saved registers are saved around them)."""
+    funcs, cur = {}, None
+    for line in disassemble(lib_path).splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if cur is not None and "\t" in line:
+            cur.append(line)
+    out = {}
+    off_re = re.compile(r"//\s*([0-9A-Fa-f]+):")
+    for name, lines in funcs.items():
+        if name_filter not in name or not lines:
+            continue
+        base = int(off_re.search(lines[0]).group(1), 16)
+        rows = []
+        for l in lines:
+            mo = off_re.search(l)
+            if mo:
+                rows.append((int(mo.group(1), 16) - base, l.split("\t")[1].strip() if len(l.split("\t")) > 1 else ""))
+        lo = hi = None
+        for off, op in rows:
+            if op.startswith(("s_cbranch", "s_branch")):
+                mt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", op)
+                if mt and int(mt.group(1), 16) < off and off - int(mt.group(1), 16) > 200:
+                    lo, hi = int(mt.group(1), 16), off
+        inl = [op for off, op in rows if lo is not None and lo <= off <= hi]
+        out[name] = dict(insts=len(rows), scratch=sum(op.startswith("scratch_") for _, op in rows), loop=(lo, hi),
+                         scratch_in_loop=sum(op.startswith("scratch_") for op in inl), valu_in_loop=sum(op.startswith("v_") for op in inl),
+                         lds_in_loop=sum(op.startswith("ds_") for op in inl), vmem_in_loop=sum(op.startswith(("global_", "flat_", "buffer_")) for op in inl))
+    return out
+
+
 if __name__ == "__main__":
     import sys
     from .build import LIB

@@ -93,14 +93,22 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
            and "RowLdsIfLi64" not in n]
     assert len(hot) >= 10, sorted(st)[:5]          # 5 phases x 2 robots
     for n in hot:
-        assert st[n]["scratch"] <= 4, (n, st[n])   # (a couple of callee-saved registers around the rare cap_contacts call)
+        assert st[n]["scratch"] <= 8, (n, st[n])   # (four callee-saved registers around the rare cap_contacts call; at two wavefronts per SIMD there are no AGPRs to park them in)
         assert st[n]["flat"] <= 11, (n, st[n])     # phase_leg_rt reads PhysParams fields (9 + the treadmill friction, twice) through its reference argument
         assert st[n]["global"] == 0, (n, st[n])
-    sweeps = {n: s for n, s in st.items() if "pgs_team_variantIfNS" in n}
+    # the 17 specialised sweeps: whatever their register pressure (the heaviest save callee-saved registers to scratch
+    # around the body now that the kernel is held to 256 registers for two wavefronts per SIMD), the 50-sweep LOOP itself
+    # is register-only -- no scratch, no LDS, no global or FLAT access -- at 25 VALU instructions per slot
+    sweeps = devcode.loop_stats(build.LIB, "pgs_team_variantIfNS")
     assert len(sweeps) == 17
     for n, s in sweeps.items():
         m = re.search(r"Li(\d)ELi(\d)ELi(\d)EEE", n)
         lim, nn, nf = (int(x) for x in m.groups())
-        assert s["flat"] == 0 and s["global"] == 0
-        if nf <= 5 or (nf == 6 and lim == 0):
-            assert s["scratch"] <= 2, (n, s)       # (at most one callee-saved VGPR saved / restored around the body, none in the sweep loop)
+        nslots = lim + nn + nf
+        if nn + nf == 0:
+            continue                       # (the limit-only sweep is unrolled differently; it is 1 slot)
+        assert s["loop"][0] is not None, n
+        assert s["scratch_in_loop"] == 0 and s["lds_in_loop"] == 0 and s["vmem_in_loop"] == 0, (n, s)
+        assert s["valu_in_loop"] <= 26 * nslots, (n, s)
+        if nf <= 4:
+            assert s["scratch"] <= 2, (n, s)
