@@ -90,6 +90,13 @@ typedef struct solorl_config {
   double treadmill_offset;      /* 0.49 (simulation.py:49) */
   double treadmill_half_width;  /* 0.5: (numHeightfieldColumns - 1) / 2 grid units */
   double treadmill_friction;    /* 0.5: Bullet's default lateral friction of the heightfield body */
+  /* PyBullet's solverResidualThreshold (1e-7 there): the PGS loop of a sub-step ends after the
+   * first iteration whose largest squared velocity-level change, max_rows (delta_impulse / jacDiagABInv)^2, is <= this
+   * value (or after solver_iterations).  Default 0 = always run solver_iterations sweeps: with this engine's stateless
+   * one-point-per-primitive contact set the threshold stops most solves after 3-10 sweeps, and a PD-held stance that is
+   * stable at 50 sweeps then is not -- whether PyBullet's persistent 4-point manifolds behave
+   * the same cannot be checked here, so the early exit is implemented (oracle and engine, parity-tested) but opt-in. */
+  double solver_residual_threshold;
 } solorl_config;
 
 /* Struct-of-arrays info block (replaces the per-env dicts of baseEnv.py:62-66).  Every pointer is

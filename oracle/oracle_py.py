@@ -37,6 +37,8 @@ def lib():
                      "oracle_prim_points", "oracle_last_lambda", "oracle_philox", "oracle_euler_from_quat"):
             getattr(L, name).restype = None
         L.oracle_increment_curriculum.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_last_iterations.restype = C.c_int
+        L.oracle_last_iterations.argtypes = [C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -118,6 +120,9 @@ class Oracle:
         o = np.zeros((self.np, 4))
         self.L.oracle_prim_points(self.h, i, _p(o))
         return o
+
+    def last_iterations(self, i=0):
+        return int(self.L.oracle_last_iterations(self.h, int(i)))
 
     def last_lambda(self, i=0):
         o = np.zeros(self.np)

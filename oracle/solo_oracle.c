@@ -109,6 +109,7 @@ struct oracle_env {
   double inertia[NL_MAX][6]; /* link inertia about COM in link axes: xx yy zz xy xz yz */
   solorl_env_state* st;
   double (*last_lambda)[NP_MAX];
+  int* last_iterations;          /* PGS iterations the last sub-step of each env ran (early exit, K7) */
 };
 
 typedef struct {
@@ -360,6 +361,7 @@ static void substep(oracle_env* E, int ei) {
     for (int k = 0; k < nv; k++) dV[k] += r->B[k] * r->lam;
   }
   for (int it = 0; it < C->solver_iterations; it++) {
+    double resid = 0;   /* K7: btMultiBodyConstraintSolver::solveSingleIteration's leastSquaresResidual = max (deltaImpulse / jacDiagABInv)^2 */
     for (int i = 0; i < nr; i++) {
       row_t* r = &rows[i];
       double jdv = 0;
@@ -369,8 +371,13 @@ static void substep(oracle_env* E, int ei) {
       if (sum < lo) sum = lo; if (sum > hi) sum = hi;
       delta = sum - r->lam; r->lam = sum;
       for (int k = 0; k < nv; k++) dV[k] += r->B[k] * delta;
+      { double dvel = delta / r->dinv; if (dvel * dvel > resid) resid = dvel * dvel; }
     }
+    E->last_iterations[ei] = it + 1;
+    /* solveGroupCacheFriendlyIterations: stop once the residual is within solverResidualThreshold (PyBullet default 1e-7) */
+    if (C->solver_residual_threshold > 0 && resid <= C->solver_residual_threshold) break;
   }
+  if (nr == 0) E->last_iterations[ei] = 0;
   for (int k = 0; k < nv; k++) { u[k] += dV[k]; clampv(&u[k], C->max_velocity); }
   for (int p = 0; p < E->np; p++) { s->lambda_prev[p] = 0; E->last_lambda[ei][p] = 0; }
   s->contact_mask = 0;
@@ -567,10 +574,12 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   }
   E->st = (solorl_env_state*)calloc((size_t)num_envs, sizeof *E->st);
   E->last_lambda = calloc((size_t)num_envs, sizeof *E->last_lambda);
+  E->last_iterations = calloc((size_t)num_envs, sizeof *E->last_iterations);
   for (int i = 0; i < num_envs; i++) { E->st[i].quat[3] = 1; E->st[i].pos[2] = 0.35; E->st[i].need_reset = 1; }
   return E;
 }
-void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E); }
+void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E->last_iterations); free(E); }
+int oracle_last_iterations(const oracle_env* E, int i) { return E->last_iterations[i]; }
 void oracle_dims(const oracle_env* E, int* o, int* a, int* n) { if (o) *o = E->O; if (a) *a = E->n; if (n) *n = E->N; }
 void oracle_set_threads(oracle_env* E, int t) { E->nthreads = t < 1 ? 1 : t; }
 void oracle_reset(oracle_env* E, double* obs) {

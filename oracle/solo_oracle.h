@@ -48,6 +48,8 @@ void oracle_energy_momentum(const oracle_env* e, int i, double* out8);
 void oracle_prim_points(const oracle_env* e, int i, double* out);
 /* last solve of env i: number of rows, and per active primitive the normal impulse */
 void oracle_last_lambda(const oracle_env* e, int i, double* lambda_n /* [nprims] */);
+/* PGS iterations the last sub-step of env i ran (<= solver_iterations: early exit on the residual threshold, K7) */
+int oracle_last_iterations(const oracle_env* e, int i);
 /* Philox4x32-10 (for RNG parity tests) */
 void oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                    uint32_t out[4]);

@@ -33,6 +33,7 @@ class SoloConfig(C.Structure):
         ("linear_slop", C.c_double), ("warmstart", C.c_double), ("damping", C.c_double),
         ("max_velocity", C.c_double), ("joint_limit", C.c_double), ("goal_radius", C.c_double),
         ("treadmill_offset", C.c_double), ("treadmill_half_width", C.c_double), ("treadmill_friction", C.c_double),
+        ("solver_residual_threshold", C.c_double),
     ]
 
     @property
@@ -91,6 +92,7 @@ def default_config(robot=ROBOT_SOLO12, task=TASK_WALK):
     c.erp, c.linear_slop, c.warmstart, c.damping = 0.2, 1e-5, 0.85, 0.04
     c.max_velocity, c.joint_limit, c.goal_radius = 100.0, 10.0, 2.0
     c.use_treadmill, c.treadmill_offset, c.treadmill_half_width, c.treadmill_friction = 0, 0.49, 0.5, 0.5
+    c.solver_residual_threshold = 0.0       # K7 early exit off: see include/solorl.h
     return c
 
 
@@ -141,7 +143,7 @@ def config_from_dict(d, **overrides):
         c.kp, c.kd = float(gains[0]), float(gains[1])
     for k in ("hold_torque", "use_urdf_inertia", "solver_iterations", "disable_termination", "settle_min",
               "settle_max", "precision", "warmstart", "erp", "damping", "reward_dt", "goal_radius", "treadmill_offset",
-              "treadmill_half_width", "treadmill_friction"):
+              "treadmill_half_width", "treadmill_friction", "solver_residual_threshold"):
         if k in d:
             setattr(c, k, type(getattr(c, k))(d[k]))
     return c

@@ -76,6 +76,7 @@ template <typename T> struct PhysParams {
   T dt, gravity, erp, slop, warm, damping, vmax, qlim, inv_dt;
   int iterations;
   int tm_on; T tm_hw, tm_mu;   // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
+  T resid_thr;                 // sqrt(solver_residual_threshold): velocity-level change below which a solve stops (K7); < 0: never
 };
 // bit 20+f of a sub-step's returned mask: foot f's contact lies on the treadmill strip (foot primitive = 13 + 2f)
 SD int strip_feet_bits(int smask) {
@@ -866,7 +867,7 @@ SNI void phase_base(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned n
 // parent is found arithmetically (parent = nlim + (r - nlim - nc)/2), so there is no dependent
 // LDS chain.  Accumulators: base delta-velocity w in registers, leg delta-rates y in LDS.
 template <typename T, int ROBOT, typename LDS, typename CH>
-SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
+SNI void phase_pgs(CH ch, int iterations, T resid_thr, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using R_ = LDS;
   using Chunk = typename R_::Chunk;
@@ -887,6 +888,7 @@ SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
   // r is computed; if r+1 works on the same leg (or has row r as friction parent) the freshly
   // computed register values are forwarded instead of waiting for an LDS store->load round trip.
   struct Row { T c[ROW_CORE]; T mu, lam, lamp, y0, y1, y2; int yoff, par; };
+  bool conv = false, viol = false;
   auto fetch = [&](int rr, Row& R) {
     const Chunk* p = corev + __mul24(rr, NCH * LN);
 #pragma unroll
@@ -913,8 +915,10 @@ SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
     const T lo = fr ? -hi : T(0);
     T sum = R.lam + (R.c[18] - jdv * R.c[19]);
     sum = sum < lo ? lo : (sum > hi ? hi : sum);
-    sum = live ? sum : R.lam;
+    sum = (live && !conv) ? sum : R.lam;                  // (a converged lane's solve is over: its rows stay as they are)
     const T delta = sum - R.lam;
+    const T dvel = fabs(delta) / R.c[19];                  // K7 residual: |delta impulse| / jacDiagABInv
+    viol = viol || (dvel > resid_thr);
     w.a.x += R.c[9] * delta; w.a.y += R.c[10] * delta; w.a.z += R.c[11] * delta;
     w.l.x += R.c[12] * delta; w.l.y += R.c[13] * delta; w.l.z += R.c[14] * delta;
     const T y0 = R.y0 + R.c[15] * delta, y1 = R.y1 + R.c[16] * delta, y2 = R.y2 + R.c[17] * delta;
@@ -931,11 +935,14 @@ SNI void phase_pgs(CH ch, int iterations, const LDS lds) {
   for (int it = 0; it < iterations; it++) {
     Row A, B;
     fetch(0, A);
+    viol = false;
 #pragma unroll 1
     for (int r = 0; r < wmax; r += 2) {  // ping-pong: no register rotation
       step(r, A, B);
       step(r + 1, B, A);
     }
+    conv = conv || !viol;               // K7: this lane's solve ends after the first sweep within the residual threshold
+    if (!__any(!conv)) break;
   }
   C.w = w;
 #pragma unroll
@@ -1287,6 +1294,7 @@ SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) 
     o[E_RHS] = rhs / sB;                // finish_row's rhs already carries 1/diag
     o[E_LEG] = T(leg);
     lds.store_core(r, o);
+    lds.A(r, LDS::A_LAM) = pp.resid_thr * sJ;      // K7 in the row's units: |delta lambda~| / sJ = |delta impulse| / jacDiagABInv
     lam[TRW::pos_of(r, nlt, nc) * 4] = c[13];      // warm-start impulse (0 for friction / limit rows)
   };
   emit(t, c0, meta0, mu0);
@@ -1328,8 +1336,10 @@ template <typename T> SD T team_red8(T x) {      // sum over the 8 lanes of a ha
   return x;
 }
 
-template <typename T, typename LDS, int LIM, int NNS, int NFS>
+// EXIT: with the K7 residual test (solver_residual_threshold > 0); the default fixed-iteration solve carries none of it.
+template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT>
 SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
+  // (the residual threshold of K7 reaches the sweep through the rows: phase_finish_team stores it per row, in the row's units)
   using TRW = TeamRows<T, LDS>;
   const int iterations = __builtin_amdgcn_readfirstlane(iterations_v);   // function arguments arrive in VGPRs: make the sweep loop scalar
   constexpr int LN = LDS::LANES, n = LIM + NNS + NFS;
@@ -1357,7 +1367,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     return *reinterpret_cast<const T*>(solo_smem + ((unsigned)((r * LDS::NCH + e / LDS::PER) * LN + col) * 16u + (unsigned)(e % LDS::PER) * SZ));
   };
   // all arrays below are indexed by the sweep index i
-  T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
+  T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n], th[n];
   T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
   T a0 = T(0), a1 = T(0), a2 = T(0);
   static_for<n>([&](auto ic) {
@@ -1374,6 +1384,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     J0[i] = uo ? ju : T(0); B0[i] = uo ? bu : T(0); J1[i] = vo ? jv : T(0); B1[i] = vo ? bv : T(0); J2[i] = wo ? jw : T(0); B2[i] = wo ? bw : T(0);
     X0[i] = ux ? xu : T(0); X1[i] = vx ? xv : T(0); X2[i] = wx ? xw : T(0);
     rh[i] = r_own >= 0 ? rhs : T(0);
+    if constexpr (EXIT) th[i] = r_own >= 0 ? lds.A(ro, LDS::A_LAM) : T(0);      // |delta| above which this row keeps its team iterating
+    else th[i] = T(0);
     // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
     // partner's B~; half 0 takes 0 (its row does not wait for anybody)
     const T c = team_red8(J0[i] * X0[i] + J1[i] * X1[i] + J2[i] * X2[i]);
@@ -1392,8 +1404,29 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   });
   T dpre = team_red8(J0[0] * a0 + J1[0] * a1 + J2[0] * a2);
   T delp = T(0), delxp = T(0);
+  // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
+  T* const hdr = lds.hdr();
+  auto write_back = [&]() __attribute__((always_inline)) {
+    if (h == 0) {
+      static_for<n>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        *reinterpret_cast<T*>(solo_smem + lam_own + 2 * Ord::slot(i) * S_LAM) = lm[i];
+      });
+    }
+    if (half == 0) {
+      if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0;
+      lds.y()[(h + 2) * LN] = a1;
+      if (h < 2) lds.y()[(10 + h) * LN] = a2;
+    }
+  };
+  // K7 early exit, per env as in the reference (one Bullet world per env): a team whose sweep changed no row by more
+  // than the threshold is finished -- its result is written back right then (it keeps sweeping along with its wavefront,
+  // which costs nothing and is never read) -- and the wavefront leaves the loop once all four teams are finished.
+  const unsigned team_bit = 1u << col;                                // this lane's team
+  unsigned finished = 0;                                              // wave-uniform set of finished teams (4 bits)
 #pragma unroll 1
   for (int it = 0; it < iterations; it++) {
+    bool viol = false;
     static_for<n>([&](auto ic) {
       constexpr int i = decltype(ic)::value, in = (i + 1) % n;
       constexpr bool fric = i >= LIM + NNS;
@@ -1421,6 +1454,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       sp -= cp[i] * half_swap(dfirst);
       const T sv = clampb(sp);
       const T del = sv - lm[i];
+      if constexpr (EXIT) viol = viol || (fabs(del) > th[i]);
       lm[i] = sv;
       const T delx = half_swap(del);
       if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] += delx;
@@ -1429,27 +1463,28 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       a2 += B2[i] * del + X2[i] * delx;
       dpre = dnext; delp = del; delxp = delx;
     });
+    if constexpr (EXIT) {
+      // lanes of a team sit in one 16-lane row of the wavefront: bits 16c .. 16c+15 of the ballot belong to team c
+      const unsigned long long vm = __ballot(viol);
+      unsigned quiet = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) quiet |= ((unsigned)(vm >> (16 * c)) & 0xFFFFu) == 0u ? (1u << c) : 0u;
+      const unsigned newly = quiet & ~finished;
+      if (newly) {                                       // (wave-uniform branch, taken at most once per team)
+        if (newly & team_bit) write_back();
+        finished |= newly;
+        if (finished == 0xFu) break;
+      }
+    }
   }
-  // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
-  if (h == 0) {
-    static_for<n>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      *reinterpret_cast<T*>(solo_smem + lam_own + 2 * Ord::slot(i) * S_LAM) = lm[i];
-    });
-  }
-  T* const hdr = lds.hdr();
-  if (half == 0) {
-    if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0;
-    lds.y()[(h + 2) * LN] = a1;
-    if (h < 2) lds.y()[(10 + h) * LN] = a2;
-  }
+  if (!(finished & team_bit)) write_back();            // teams that ran all the iterations
 }
 
 #ifdef SOLO_PHASE_TIMING
 __device__ unsigned long long solo_pgs_cycles[2][10];     // [cycles | calls][wave's largest contact count]
 #endif
 template <typename T, int ROBOT, typename LDS>
-SD void phase_pgs_team(int iterations, const LDS lds, int t) {
+SD void phase_pgs_team(int iterations, bool early_exit, const LDS lds, int t) {
   constexpr int LN = LDS::LANES;
   int nlt, nc, ncmax, anylim;
   team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
@@ -1462,11 +1497,13 @@ SD void phase_pgs_team(int iterations, const LDS lds, int t) {
     if ((unsigned long long)ncmax > solo_wave_times[blockIdx.x][5]) solo_wave_times[blockIdx.x][5] = (unsigned long long)ncmax;
   }
 #endif
-#define SOLO_SWEEP_L(N_, F_) do { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_>(iterations, lds, t); \
-                                  else pgs_team_variant<T, LDS, 0, N_, F_>(iterations, lds, t); } while (0)
+#define SOLO_SWEEP_L(N_, F_) do { if (early_exit) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, true>(iterations, lds, t); \
+                                                    else pgs_team_variant<T, LDS, 0, N_, F_, true>(iterations, lds, t); } \
+                                  else { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false>(iterations, lds, t); \
+                                         else pgs_team_variant<T, LDS, 0, N_, F_, false>(iterations, lds, t); } } while (0)
   switch (ncmax) {       // wave-uniform
     case 0:
-      if (anylim) pgs_team_variant<T, LDS, 1, 0, 0>(iterations, lds, t);
+      if (anylim) { if (early_exit) pgs_team_variant<T, LDS, 1, 0, 0, true>(iterations, lds, t); else pgs_team_variant<T, LDS, 1, 0, 0, false>(iterations, lds, t); }
       else {             // no rows at all: the accumulators the leader reads back are zero
         const int h = t & 7;
         T* const hdr = lds.hdr();
@@ -1588,7 +1625,7 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #endif
   SOLO_TICK(3);
-  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, lds, t);
+  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.resid_thr >= T(0), lds, t);
   SOLO_TICK(5);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
   SOLO_TICK(6);
@@ -1609,7 +1646,7 @@ SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, T* lam_prev, unsigne
   phase_leg<T, ROBOT, 2, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   phase_leg<T, ROBOT, 3, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   phase_base<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, lds);
+  phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, pp.resid_thr, lds);
   phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   return C.mask | strip_feet_bits(C.smask);
 }

@@ -788,6 +788,7 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   p.damping = (T)c.damping; p.vmax = (T)c.max_velocity; p.qlim = (T)c.joint_limit; p.inv_dt = (T)(1.0 / c.sim_dt);
   p.iterations = c.solver_iterations;
   p.tm_on = c.use_treadmill; p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
+  p.resid_thr = c.solver_residual_threshold > 0 ? (T)sqrt(c.solver_residual_threshold) : T(-1);
   return p;
 }
 
@@ -870,6 +871,7 @@ int check_cfg(const solorl_config* c) {
   if (c->use_urdf_inertia) return fail(SOLORL_ERR_INVALID, "use_urdf_inertia=1 is not implemented by the HIP engine (box inertia, K2, only)");
   if (!(c->sim_dt > 0) || !(c->goal_radius > 1.0)) return fail(SOLORL_ERR_INVALID, "sim_dt must be > 0 and goal_radius > 1");
   if (c->use_treadmill && !(c->treadmill_half_width > 0 && c->treadmill_friction >= 0)) return fail(SOLORL_ERR_INVALID, "bad treadmill parameters");
+  if (!(c->solver_residual_threshold >= 0)) return fail(SOLORL_ERR_INVALID, "solver_residual_threshold must be >= 0");
   if (c->precision != SOLORL_PRECISION_F32 && c->precision != SOLORL_PRECISION_F64) return fail(SOLORL_ERR_INVALID, "bad precision");
   return 0;
 }
@@ -959,6 +961,7 @@ int solorl_default_config(solorl_config* c, int robot, int task) {
   c->erp = 0.2; c->linear_slop = 1e-5; c->warmstart = 0.85; c->damping = 0.04; c->max_velocity = 100.0;
   c->joint_limit = 10.0; c->goal_radius = 2.0;
   c->use_treadmill = 0; c->treadmill_offset = 0.49; c->treadmill_half_width = 0.5; c->treadmill_friction = 0.5;
+  c->solver_residual_threshold = 0.0;
   return 0;
 }
 

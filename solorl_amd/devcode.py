@@ -40,8 +40,8 @@ def function_stats(lib_path):
 
 
 def loop_stats(lib_path, name_filter):
-    """For every function whose mangled name contains `name_filter`: the outermost backward branch spanning more than
-    200 bytes is taken as THE loop; returns {name: {"insts", "scratch", "scratch_in_loop", "valu_in_loop", "lds_in_loop"}}.
+    """For every function whose mangled name contains `name_filter`: the widest backward branch (spanning more than
+    200 bytes) is taken as THE loop; returns {name: {"insts", "scratch", "scratch_in_loop", "valu_in_loop", "lds_in_loop"}}.
     Used to pin that the PGS sweep loops touch no memory at all (callee-saved registers are saved around them)."""
     funcs, cur = {}, None
     for line in disassemble(lib_path).splitlines():
@@ -67,11 +67,13 @@ def loop_stats(lib_path, name_filter):
             if op.startswith(("s_cbranch", "s_branch")):
                 mt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", op)
                 if mt and int(mt.group(1), 16) < off and off - int(mt.group(1), 16) > 200:
-                    lo, hi = int(mt.group(1), 16), off
+                    if lo is None or off - int(mt.group(1), 16) > hi - lo:         # the widest backward branch = the sweep loop
+                        lo, hi = int(mt.group(1), 16), off
         inl = [op for off, op in rows if lo is not None and lo <= off <= hi]
         out[name] = dict(insts=len(rows), scratch=sum(op.startswith("scratch_") for _, op in rows), loop=(lo, hi),
                          scratch_in_loop=sum(op.startswith("scratch_") for op in inl), valu_in_loop=sum(op.startswith("v_") for op in inl),
-                         lds_in_loop=sum(op.startswith("ds_") for op in inl), vmem_in_loop=sum(op.startswith(("global_", "flat_", "buffer_")) for op in inl))
+                         lds_in_loop=sum(op.startswith("ds_") for op in inl), lds_reads_in_loop=sum(op.startswith("ds_read") for op in inl),
+                         vmem_in_loop=sum(op.startswith(("global_", "flat_", "buffer_")) for op in inl))
     return out
 
 

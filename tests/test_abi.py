@@ -34,7 +34,7 @@ def test_default_config_matches_python_mirror(lib):
             c = SoloConfig()
             assert lib.solorl_default_config(C.byref(c), robot, task) == 0
             assert bytes(c) == bytes(default_config(robot, task))
-    assert C.sizeof(SoloConfig) == 14 * 4 + 16 * 8
+    assert C.sizeof(SoloConfig) == 14 * 4 + 17 * 8
     assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 20 + 2 * 42 + 2 + 4 + 5 + 1) + 4 * 4
 
 
@@ -97,18 +97,22 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
         assert st[n]["flat"] <= 11, (n, st[n])     # phase_leg_rt reads PhysParams fields (9 + the treadmill friction, twice) through its reference argument
         assert st[n]["global"] == 0, (n, st[n])
     # the 17 specialised sweeps: whatever their register pressure (the heaviest save callee-saved registers to scratch
-    # around the body now that the kernel is held to 256 registers for two wavefronts per SIMD), the 50-sweep LOOP itself
-    # is register-only -- no scratch, no LDS, no global or FLAT access -- at 25 VALU instructions per slot
+    # around the body now that the kernel is held to 256 registers for two wavefronts per SIMD), the sweep LOOP itself
+    # is register-only -- no scratch, no LDS read, no global or FLAT access (its only LDS writes are the cold block that
+    # publishes a team's result when its residual falls below the K7 threshold) -- at 26 VALU instructions per slot
     sweeps = devcode.loop_stats(build.LIB, "pgs_team_variantIfNS")
-    assert len(sweeps) == 17
+    assert len(sweeps) == 34               # 17 slot sets x {fixed iteration count (default), K7 residual exit}
     for n, s in sweeps.items():
-        m = re.search(r"Li(\d)ELi(\d)ELi(\d)EEE", n)
-        lim, nn, nf = (int(x) for x in m.groups())
+        m = re.search(r"Li(\d)ELi(\d)ELi(\d)ELb(\d)EEE", n)
+        lim, nn, nf, early = (int(x) for x in m.groups())
         nslots = lim + nn + nf
         if nn + nf == 0:
-            continue                       # (the limit-only sweep is unrolled differently; it is 1 slot)
+            continue                       # (the limit-only sweep is 1 slot)
         assert s["loop"][0] is not None, n
-        assert s["scratch_in_loop"] == 0 and s["lds_in_loop"] == 0 and s["vmem_in_loop"] == 0, (n, s)
-        assert s["valu_in_loop"] <= 26 * nslots, (n, s)
+        assert s["scratch_in_loop"] == 0 and s["lds_reads_in_loop"] == 0 and s["vmem_in_loop"] == 0, (n, s)
+        if early:
+            assert s["valu_in_loop"] <= 27 * nslots + 16, (n, s)
+        else:
+            assert s["lds_in_loop"] == 0 and s["valu_in_loop"] <= 27 * nslots, (n, s)
         if nf <= 4:
-            assert s["scratch"] <= 2, (n, s)
+            assert s["scratch"] <= 6, (n, s)       # callee-saved VGPR saves around the body only

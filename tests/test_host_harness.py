@@ -62,7 +62,9 @@ def test_contact_substeps_resynced(robot, n, treadmill):
         e32.append(np.abs(state_vec(a, n) - state_vec(h32, n)).max())
     e64, e32 = np.array(e64), np.array(e32)
     assert saw_contacts > 100 and (strip > 20 if treadmill else strip == 0)
-    assert np.median(e64) < 1e-11 and np.percentile(e64, 90) < 1e-8 and e64.max() < 1e-3
+    # (max: a solve whose residual sits at the K7 threshold may stop one sweep earlier in one implementation than in the
+    # other; the continuing one then moves on by about the threshold, 3e-4 m/s, per sweep)
+    assert np.median(e64) < 1e-11 and np.percentile(e64, 90) < 1e-8 and e64.max() < 2e-2
     assert np.median(e32) < 2e-4 and np.percentile(e32, 90) < 2e-2
 
 
@@ -132,3 +134,37 @@ def test_walk_torque_parity_input_divergence_horizon():
     assert h64 >= 55, h64
     assert h32 >= 12, h32
     assert max(dq[False][:10]) < 1e-11 and max(dq[True][:10]) < 5e-4          # before the fall: rounding only
+
+
+@pytest.mark.parametrize("robot,n", [(ROBOT_SOLO8, 8), (ROBOT_SOLO12, 12)])
+def test_residual_threshold_early_exit_matches_oracle(robot, n):
+    """SURVEY Appendix B K7 / PyBullet's solverResidualThreshold (opt-in, include/solorl.h): the PGS loop of a sub-step
+    stops after the first sweep whose largest velocity-level change is within sqrt(1e-7) = 3.2e-4.  Same thrashing
+    robot as test_contact_substeps_resynced: oracle and kernel math stop after the same sweep (errors stay at rounding),
+    most solves stop long before 50 sweeps, and the truncated result is within a few thresholds of the full solve."""
+    c = default_config(robot, TASK_WALK); c.solver_residual_threshold = 1e-7
+    cfull = default_config(robot, TASK_WALK)
+    assert cfull.solver_residual_threshold == 0.0            # default: fixed 50 sweeps
+    rng = np.random.default_rng(1)
+    o, ofull = Oracle(c, 1), Oracle(cfull, 1)
+    e64, its, trunc = [], [], []
+    for k in range(400):
+        so = o.get_state(0)
+        if k % 4 == 0:
+            tau = rng.uniform(-1.0, 1.0, size=n)
+        for j in range(n):
+            so.tau[j] = tau[j] if k % 4 == 0 else 0.0
+        o.set_state(0, so); ofull.set_state(0, clone(so))
+        h64 = clone(so)
+        o.substep(0); ofull.substep(0)
+        harness_py.substep(h64, c, False)
+        a = o.get_state(0)
+        assert a.contact_mask == h64.contact_mask and ofull.last_iterations(0) in (0, 50)
+        if a.contact_mask:
+            its.append(o.last_iterations(0))
+            trunc.append(np.abs(state_vec(a, n) - state_vec(ofull.get_state(0), n)).max())
+        e64.append(np.abs(state_vec(a, n) - state_vec(h64, n)).max())
+    e64, its, trunc = np.array(e64), np.array(its), np.array(trunc)
+    assert len(its) > 100 and np.median(its) <= 15 and its.max() <= 50 and (its < 50).mean() > 0.7
+    assert np.median(e64) < 1e-11 and np.percentile(e64, 95) < 1e-8           # same exit sweep in both implementations
+    assert np.median(trunc) < 2e-3                                            # velocities within a few thresholds of the full solve

@@ -360,3 +360,43 @@ def test_episode_stat_accumulators(gpu_device):
             assert abs(mine - theirs) < 2.0, (name, mine, theirs)   # chaotic episodes is dominated by a few events (quantiles: test_rollout_statistics_match_oracle)
         else:
             assert abs(mine - theirs) < 0.1 * abs(theirs) + 0.05, (name, mine, theirs)
+
+
+# ------------------------------------------------------------------------------------------------ K7 early exit (opt-in)
+@pytest.mark.parametrize("team", [1, 0])
+def test_residual_threshold_early_exit_vs_oracle(gpu_device, team):
+    """solver_residual_threshold = 1e-7 (PyBullet's solverResidualThreshold, SURVEY Appendix B K7; opt-in): every env's
+    solve ends after the first sweep within the threshold -- per env, also when the four envs of a team-mode wavefront
+    finish after different sweeps.  Resynced against the oracle running the same rule; team mode (default) and lane mode."""
+    from solorl_amd.vec_env import SoloVecEnv
+    from oracle.oracle_py import Oracle
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK, solver_residual_threshold=1e-7)
+    N = 128
+    os.environ["SOLORL_TEAM"] = str(team)
+    try:
+        env = SoloVecEnv(c, N, device="cuda:0", seed=3)
+    finally:
+        del os.environ["SOLORL_TEAM"]
+    orc = Oracle(c, N, seed=3, threads=8)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(0)
+    dq, its, mism = [], [], 0
+    for t in range(30):
+        resync(orc, env, N)
+        a = rng.uniform(-1.2, 1.2, size=(N, 12)).astype(np.float32) * (0.3 if t < 15 else 1.0)
+        _, _, done, _ = env.step(torch.from_numpy(a).cuda())
+        _, _, odone, _ = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy()
+        for i in range(N):
+            if done[i] or odone[i]:
+                continue
+            sg, so = env.get_state(i), orc.get_state(i)
+            dq.append(np.abs(np.array(sg.q) - np.array(so.q)).max()); mism += sg.contact_mask != so.contact_mask
+            if so.contact_mask:
+                its.append(orc.last_iterations(i))
+    dq, its = np.array(dq), np.array(its)
+    print("early exit (%s mode): median |dq| %.1e, p90 %.1e; oracle sweeps per solve: median %d, %.0f %% below 50" % (
+        "team" if team else "lane", np.median(dq), np.percentile(dq, 90), np.median(its), 100 * (its < 50).mean()))
+    assert np.median(its) < 20 and (its < 50).mean() > 0.6
+    assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 2e-3, (np.median(dq), np.percentile(dq, 90))
+    assert mism <= 0.02 * len(dq)
