@@ -1367,7 +1367,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     return *reinterpret_cast<const T*>(solo_smem + ((unsigned)((r * LDS::NCH + e / LDS::PER) * LN + col) * 16u + (unsigned)(e % LDS::PER) * SZ));
   };
   // all arrays below are indexed by the sweep index i
-  T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n], th[n];
+  T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
+  T th[EXIT ? n : 1];                            // (K7) |delta| above which a row keeps its team iterating
   T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
   T a0 = T(0), a1 = T(0), a2 = T(0);
   static_for<n>([&](auto ic) {
@@ -1384,8 +1385,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     J0[i] = uo ? ju : T(0); B0[i] = uo ? bu : T(0); J1[i] = vo ? jv : T(0); B1[i] = vo ? bv : T(0); J2[i] = wo ? jw : T(0); B2[i] = wo ? bw : T(0);
     X0[i] = ux ? xu : T(0); X1[i] = vx ? xv : T(0); X2[i] = wx ? xw : T(0);
     rh[i] = r_own >= 0 ? rhs : T(0);
-    if constexpr (EXIT) th[i] = r_own >= 0 ? lds.A(ro, LDS::A_LAM) : T(0);      // |delta| above which this row keeps its team iterating
-    else th[i] = T(0);
+    if constexpr (EXIT) th[i] = r_own >= 0 ? lds.A(ro, LDS::A_LAM) : T(0);
     // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
     // partner's B~; half 0 takes 0 (its row does not wait for anybody)
     const T c = team_red8(J0[i] * X0[i] + J1[i] * X1[i] + J2[i] * X2[i]);
@@ -1406,19 +1406,18 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   T delp = T(0), delxp = T(0);
   // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
   T* const hdr = lds.hdr();
-  auto write_back = [&]() __attribute__((always_inline)) {
-    if (h == 0) {
-      static_for<n>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        *reinterpret_cast<T*>(solo_smem + lam_own + 2 * Ord::slot(i) * S_LAM) = lm[i];
-      });
-    }
-    if (half == 0) {
-      if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0;
-      lds.y()[(h + 2) * LN] = a1;
-      if (h < 2) lds.y()[(10 + h) * LN] = a2;
-    }
-  };
+#define SOLO_PGS_WRITE_BACK() do { \
+    if (h == 0) { \
+      static_for<n>([&](auto ic_) { \
+        constexpr int i_ = decltype(ic_)::value; \
+        *reinterpret_cast<T*>(solo_smem + lam_own + 2 * Ord::slot(i_) * S_LAM) = lm[i_]; \
+      }); \
+    } \
+    if (half == 0) { \
+      if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0; \
+      lds.y()[(h + 2) * LN] = a1; \
+      if (h < 2) lds.y()[(10 + h) * LN] = a2; \
+    } } while (0)
   // K7 early exit, per env as in the reference (one Bullet world per env): a team whose sweep changed no row by more
   // than the threshold is finished -- its result is written back right then (it keeps sweeping along with its wavefront,
   // which costs nothing and is never read) -- and the wavefront leaves the loop once all four teams are finished.
@@ -1471,13 +1470,15 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       for (int c = 0; c < 4; c++) quiet |= ((unsigned)(vm >> (16 * c)) & 0xFFFFu) == 0u ? (1u << c) : 0u;
       const unsigned newly = quiet & ~finished;
       if (newly) {                                       // (wave-uniform branch, taken at most once per team)
-        if (newly & team_bit) write_back();
+        if (newly & team_bit) SOLO_PGS_WRITE_BACK();
         finished |= newly;
         if (finished == 0xFu) break;
       }
     }
   }
-  if (!(finished & team_bit)) write_back();            // teams that ran all the iterations
+  if constexpr (EXIT) { if (!(finished & team_bit)) SOLO_PGS_WRITE_BACK(); }     // teams that ran all the iterations
+  else SOLO_PGS_WRITE_BACK();
+#undef SOLO_PGS_WRITE_BACK
 }
 
 #ifdef SOLO_PHASE_TIMING

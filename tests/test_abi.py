@@ -115,4 +115,4 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
         else:
             assert s["lds_in_loop"] == 0 and s["valu_in_loop"] <= 27 * nslots, (n, s)
         if nf <= 4:
-            assert s["scratch"] <= 6, (n, s)       # callee-saved VGPR saves around the body only
+            assert s["scratch"] <= (16 if early else 6), (n, s)       # callee-saved VGPR saves around the body only
