@@ -76,6 +76,7 @@ template <typename T> struct PhysParams {
   T dt, gravity, erp, slop, warm, damping, vmax, qlim, inv_dt;
   int iterations;
   int tm_on; T tm_hw, tm_mu;   // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
+  int urdf_inertia;            // K2: 0 = Bullet's default box inertia from the collision AABB, 1 = the URDF tensor (use_urdf_inertia)
   T resid_thr;                 // sqrt(solver_residual_threshold): velocity-level change below which a solve stops (K7); < 0: never
 };
 // bit 20+f of a sub-step's returned mask: foot f's contact lies on the treadmill strip (foot primitive = 13 + 2f)
@@ -161,8 +162,10 @@ template <typename T, int LN = default_lanes<T>()> struct RowLds {
 // R: link axes, cw: COM relative to the common origin, v: link spatial velocity.
 // Returns the link's inertia about the common origin and its bias force
 //   p = v x* I v  -  damping wrench        (gyroscopic K1 + Bullet damping K3)
-template <typename T>
-SD void link_terms(const M3<T>& R, V3<T> cw, T m, T ix, T iy, T iz, SV<T> v, T kd, RBI<T>& I, SV<T>& p) {
+// OD: bit 0 / 1 / 2 = the link tensor has an xy / xz / yz product (URDF inertia only; compile time, so the box rule pays nothing)
+template <int OD = 0, typename T>
+SD void link_terms(const M3<T>& R, V3<T> cw, T m, T ix, T iy, T iz, SV<T> v, T kd, RBI<T>& I, SV<T>& p, T ixy = T(0), T ixz = T(0),
+                   T iyz = T(0)) {
   Sym3<T> Ic;
   Ic.xx = ix * R.c0.x * R.c0.x + iy * R.c1.x * R.c1.x + iz * R.c2.x * R.c2.x;
   Ic.xy = ix * R.c0.x * R.c0.y + iy * R.c1.x * R.c1.y + iz * R.c2.x * R.c2.y;
@@ -170,6 +173,14 @@ SD void link_terms(const M3<T>& R, V3<T> cw, T m, T ix, T iy, T iz, SV<T> v, T k
   Ic.yy = ix * R.c0.y * R.c0.y + iy * R.c1.y * R.c1.y + iz * R.c2.y * R.c2.y;
   Ic.yz = ix * R.c0.y * R.c0.z + iy * R.c1.y * R.c1.z + iz * R.c2.y * R.c2.z;
   Ic.zz = ix * R.c0.z * R.c0.z + iy * R.c1.z * R.c1.z + iz * R.c2.z * R.c2.z;
+  // products of inertia: R (e_a e_b^T + e_b e_a^T) R^T = c_a c_b^T + c_b c_a^T
+  auto add_od = [&](T w, const V3<T>& a, const V3<T>& b) {
+    Ic.xx += T(2) * w * a.x * b.x; Ic.yy += T(2) * w * a.y * b.y; Ic.zz += T(2) * w * a.z * b.z;
+    Ic.xy += w * (a.x * b.y + a.y * b.x); Ic.xz += w * (a.x * b.z + a.z * b.x); Ic.yz += w * (a.y * b.z + a.z * b.y);
+  };
+  if constexpr (OD & 1) add_od(ixy, R.c0, R.c1);
+  if constexpr (OD & 2) add_od(ixz, R.c0, R.c2);
+  if constexpr (OD & 4) add_od(iyz, R.c1, R.c2);
   V3<T> vc = v.l + cross(v.a, cw);
   V3<T> Icw = mul(Ic, v.a);
   T kl = kd + kd * sqrt(dot(vc, vc));
@@ -270,6 +281,16 @@ SD void leg_prim_points(const M3<T>& R0, const T* sn, const T* cs, V3<T>& kneeP,
 
 template <typename T> SD T clampv(T x, T lim) { return x > lim ? lim : (x < -lim ? -lim : x); }
 
+// K2 inertia of a link, compile-time table entry LK: UI = false -> Bullet's box rule (diagonal), true -> the URDF tensor
+// (inertia_urdf = ixx iyy izz ixy ixz iyz; products only where the URDF has them)
+#define SOLO_LINK_TERMS_CE(UI_, LK_, R_, cw_, v_, kd_, I_, p_) do { \
+    if constexpr (UI_) { \
+      constexpr int od_ = ((LK_).inertia_urdf[3] != 0.0 ? 1 : 0) | ((LK_).inertia_urdf[4] != 0.0 ? 2 : 0) | ((LK_).inertia_urdf[5] != 0.0 ? 4 : 0); \
+      link_terms<od_>(R_, cw_, T((LK_).mass), T((LK_).inertia_urdf[0]), T((LK_).inertia_urdf[1]), T((LK_).inertia_urdf[2]), v_, kd_, I_, p_, \
+                      T((LK_).inertia_urdf[3]), T((LK_).inertia_urdf[4]), T((LK_).inertia_urdf[5])); \
+    } else link_terms(R_, cw_, T((LK_).mass), T((LK_).inertia_box[0]), T((LK_).inertia_box[1]), T((LK_).inertia_box[2]), v_, kd_, I_, p_); \
+  } while (0)
+
 // what survives of a processed leg
 template <typename T, int NJ> struct LegResp {
   SV<T> G[NJ];   // dq_k = y_k - G_k . w   (w = base delta-velocity);  qdd_k = qdd0_k - G_k . a_base
@@ -331,7 +352,7 @@ SD void park_row(const LDS& lds, int slot, SV<T> f0, const T (&JL)[3], const T (
 // ---------------------------------------------------------------- phase 1: collision detection
 // start-of-step pose (K1, K6'): support points, contact mask, MAX_CONTACTS cap, row counts
 // SINCOS_DONE: C.sn / C.cs were already filled (team mode: one joint per lane, substep_team)
-template <typename T, int ROBOT, typename CH, bool SINCOS_DONE = false>
+template <typename T, int ROBOT, typename CH, bool UI, bool SINCOS_DONE = false>
 SNI void phase_detect(CH ch, const PhysParams<T> pp) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
@@ -407,14 +428,14 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
   constexpr solorl_link_data B = RB::MD.links[0];
   static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
   RBI<T> Ib; SV<T> pb;
-  link_terms(R0, mk(T(0), T(0), T(0)), T(B.mass), T(B.inertia_box[0]), T(B.inertia_box[1]), T(B.inertia_box[2]),
-             SV<T>{st.w, st.v}, pp.damping, Ib, pb);
+  const SV<T> vb{st.w, st.v};
+  SOLO_LINK_TERMS_CE(UI, B, R0, mk(T(0), T(0), T(0)), vb, pp.damping, Ib, pb);
   C.Ibase = to_abi(Ib); C.pbase = pb;
 }
 
 // ---------------------------------------------------------------- phase 2 (x4): one leg
 // FK + ABA passes 1-2, leg response (G, qdd0), parked limit and contact rows of this leg
-template <typename T, int ROBOT, int L, typename LDS, typename CH>
+template <typename T, int ROBOT, int L, typename LDS, typename CH, bool UI>
 SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned nstride, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
@@ -446,13 +467,13 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
       SV<T> v = vp + vj;
       Sk[k] = S; ck[k] = crm(vp, vj);
       V3<T> cw = addc(o, R, LK.com[0], LK.com[1], LK.com[2]);
-      link_terms(R, cw, T(LK.mass), T(LK.inertia_box[0]), T(LK.inertia_box[1]), T(LK.inertia_box[2]), v, kd, Ik[k], pk[k]);
+      SOLO_LINK_TERMS_CE(UI, LK, R, cw, v, kd, Ik[k], pk[k]);
       if constexpr (k == NJ - 1) {  // foot: fixed child of the last link, same axes and velocity
         constexpr solorl_link_data FT = RB::MD.links[L0 + NJ];
         V3<T> of = addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]);
         V3<T> cf = addc(of, R, FT.com[0], FT.com[1], FT.com[2]);
         RBI<T> If; SV<T> pf;
-        link_terms(R, cf, T(FT.mass), T(FT.inertia_box[0]), T(FT.inertia_box[1]), T(FT.inertia_box[2]), v, kd, If, pf);
+        SOLO_LINK_TERMS_CE(UI, FT, R, cf, v, kd, If, pf);
         add(Ik[k], If); pk[k] = pk[k] + pf;
       }
       Rp = R; op = o; vp = v;
@@ -588,7 +609,7 @@ template <typename T> SD LegSign<T> leg_sign(int L) {
     else if constexpr (b_ == a_ && c_ == -a_ && d_ == -a_) return T(a_) * (g).sx; \
     else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
     else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
-template <typename T, int ROBOT, typename LDS, typename CH>
+template <typename T, int ROBOT, typename LDS, typename CH, bool UI>
 SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {   // (by reference:
                                                                      // ten more live argument registers made this phase spill 101 VGPRs)
   SubCtx<T, ROBOT>& C = ch.get();
@@ -623,12 +644,20 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       SV<T> v = vp + vj;
       Sk[k] = S; ck[k] = crm(vp, vj);
       V3<T> cw = o + mul(R, mk(LEGC(k, com[0]), LEGC(k, com[1]), LEGC(k, com[2])));
-      link_terms(R, cw, LEGC(k, mass), LEGC(k, inertia_box[0]), LEGC(k, inertia_box[1]), LEGC(k, inertia_box[2]), v, kd, Ik[k], pk[k]);
+      // K2: box rule, or the URDF tensor with its products of inertia (their signs follow the legs' mirror symmetry)
+#define LEG_OD(k_) (((RB::MD.links[1 + (k_)].inertia_urdf[3] != 0.0) ? 1 : 0) | ((RB::MD.links[1 + (k_)].inertia_urdf[4] != 0.0) ? 2 : 0) | \
+                    ((RB::MD.links[1 + (k_)].inertia_urdf[5] != 0.0) ? 4 : 0))
+      if constexpr (UI) link_terms<LEG_OD(k)>(R, cw, LEGC(k, mass), LEGC(k, inertia_urdf[0]), LEGC(k, inertia_urdf[1]), LEGC(k, inertia_urdf[2]), v, kd, Ik[k], pk[k],
+                                              LEGC(k, inertia_urdf[3]), LEGC(k, inertia_urdf[4]), LEGC(k, inertia_urdf[5]));
+      else link_terms(R, cw, LEGC(k, mass), LEGC(k, inertia_box[0]), LEGC(k, inertia_box[1]), LEGC(k, inertia_box[2]), v, kd, Ik[k], pk[k]);
       if constexpr (k == NJ - 1) {  // foot: fixed child of the last link, same axes and velocity
         V3<T> of = o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2])));
         V3<T> cf = of + mul(R, mk(LEGC(NJ, com[0]), LEGC(NJ, com[1]), LEGC(NJ, com[2])));
         RBI<T> If; SV<T> pf;
-        link_terms(R, cf, LEGC(NJ, mass), LEGC(NJ, inertia_box[0]), LEGC(NJ, inertia_box[1]), LEGC(NJ, inertia_box[2]), v, kd, If, pf);
+        if constexpr (UI) link_terms<LEG_OD(NJ)>(R, cf, LEGC(NJ, mass), LEGC(NJ, inertia_urdf[0]), LEGC(NJ, inertia_urdf[1]), LEGC(NJ, inertia_urdf[2]), v, kd, If, pf,
+                                                 LEGC(NJ, inertia_urdf[3]), LEGC(NJ, inertia_urdf[4]), LEGC(NJ, inertia_urdf[5]));
+        else link_terms(R, cf, LEGC(NJ, mass), LEGC(NJ, inertia_box[0]), LEGC(NJ, inertia_box[1]), LEGC(NJ, inertia_box[2]), v, kd, If, pf);
+#undef LEG_OD
         add(Ik[k], If); pk[k] = pk[k] + pf;
       }
       Rp = R; op = o; vp = v;
@@ -1077,7 +1106,7 @@ SNI int cap_contacts(CH ch, int mask) {
 // Collision detection, team mode (replaces phase_detect): the four legs' support points on lanes 0..3, the
 // twelve base points on lanes 4..15, joint-limit tests one joint per lane; masks are OR-reduced over the team.
 // The leader then records the counts and starts the articulated-inertia accumulation with the base link.
-template <typename T, int ROBOT, typename LDS, typename CH>
+template <typename T, int ROBOT, typename LDS, typename CH, bool UI>
 SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, int t, bool valid, bool lead) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ, NQ = RB::NQ, ST = NJ + 1;
@@ -1174,8 +1203,8 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   constexpr solorl_link_data B = RB::MD.links[0];
   static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
   RBI<T> Ib; SV<T> pb;
-  link_terms(R0, mk(T(0), T(0), T(0)), T(B.mass), T(B.inertia_box[0]), T(B.inertia_box[1]), T(B.inertia_box[2]),
-             SV<T>{st.w, st.v}, pp.damping, Ib, pb);
+  const SV<T> vb{st.w, st.v};
+  SOLO_LINK_TERMS_CE(UI, B, R0, mk(T(0), T(0), T(0)), vb, pp.damping, Ib, pb);
   C.Ibase = to_abi(Ib); C.pbase = pb;
 }
 
@@ -1601,14 +1630,19 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
     sincos_t(C.ps.q[t], sn, cs);
     C.sn[t] = sn; C.cs[t] = cs;
   }
-  phase_front_team<T, ROBOT, LDS, CH>(ch, pp, lds, t, valid, lead);
+  const bool ui = pp.urdf_inertia != 0;     // (uniform) K2: URDF tensors instead of the box rule
+  if (ui) phase_front_team<T, ROBOT, LDS, CH, true>(ch, pp, lds, t, valid, lead);
+  else phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
 #ifdef SOLO_DUP_FRONT      // dev: run an idempotent phase twice -- the launch-time delta is that phase's true cost
-  phase_front_team<T, ROBOT, LDS, CH>(ch, pp, lds, t, valid, lead);
+  phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
 #endif
   SOLO_TICK(0);
-  if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);   // four legs on four lanes
+  if (valid && t < 4) {                                                                     // four legs on four lanes
+    if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t);
+    else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
+  }
 #ifdef SOLO_DUP_LEGS
-  if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t);
+  if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
 #endif
   SOLO_TICK(1);
   if (valid) team_sum_base<T, ROBOT, CH>(ch, t);
@@ -1641,11 +1675,19 @@ template <typename T, int ROBOT, typename LDS>
 SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS& lds) {
   using CH = CtxPriv<T, ROBOT>;
   const CH ch{&C};
-  phase_detect<T, ROBOT, CH>(ch, pp);
-  phase_leg<T, ROBOT, 0, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 1, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 2, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  phase_leg<T, ROBOT, 3, LDS, CH>(ch, pp, lam_prev, nstride, lds);
+  if (pp.urdf_inertia) {
+    phase_detect<T, ROBOT, CH, true>(ch, pp);
+    phase_leg<T, ROBOT, 0, LDS, CH, true>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 1, LDS, CH, true>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 2, LDS, CH, true>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 3, LDS, CH, true>(ch, pp, lam_prev, nstride, lds);
+  } else {
+    phase_detect<T, ROBOT, CH, false>(ch, pp);
+    phase_leg<T, ROBOT, 0, LDS, CH, false>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 1, LDS, CH, false>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 2, LDS, CH, false>(ch, pp, lam_prev, nstride, lds);
+    phase_leg<T, ROBOT, 3, LDS, CH, false>(ch, pp, lam_prev, nstride, lds);
+  }
   phase_base<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, pp.resid_thr, lds);
   phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);

@@ -788,6 +788,7 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   p.damping = (T)c.damping; p.vmax = (T)c.max_velocity; p.qlim = (T)c.joint_limit; p.inv_dt = (T)(1.0 / c.sim_dt);
   p.iterations = c.solver_iterations;
   p.tm_on = c.use_treadmill; p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
+  p.urdf_inertia = c.use_urdf_inertia ? 1 : 0;
   p.resid_thr = c.solver_residual_threshold > 0 ? (T)sqrt(c.solver_residual_threshold) : T(-1);
   return p;
 }
@@ -868,7 +869,6 @@ int check_cfg(const solorl_config* c) {
   if (c->settle_min < 0 || c->settle_max < c->settle_min || c->settle_max > 64) return fail(SOLORL_ERR_INVALID, "bad settle range");
   if (c->settle_min < c->num_history_stack) return fail(SOLORL_ERR_INVALID, "settle_min must be >= num_history_stack");
   if (c->solver_iterations < 1 || c->solver_iterations > 1000) return fail(SOLORL_ERR_INVALID, "solver_iterations out of range");
-  if (c->use_urdf_inertia) return fail(SOLORL_ERR_INVALID, "use_urdf_inertia=1 is not implemented by the HIP engine (box inertia, K2, only)");
   if (!(c->sim_dt > 0) || !(c->goal_radius > 1.0)) return fail(SOLORL_ERR_INVALID, "sim_dt must be > 0 and goal_radius > 1");
   if (c->use_treadmill && !(c->treadmill_half_width > 0 && c->treadmill_friction >= 0)) return fail(SOLORL_ERR_INVALID, "bad treadmill parameters");
   if (!(c->solver_residual_threshold >= 0)) return fail(SOLORL_ERR_INVALID, "solver_residual_threshold must be >= 0");

@@ -45,7 +45,7 @@ def test_error_convention(lib):
     bad = c.copy(); bad.frame_skip = 0
     assert lib.solorl_create(C.byref(bad), 4, 0, 1, 0, C.byref(h)) == -1
     assert b"frame_skip" in lib.solorl_last_error()
-    bad = c.copy(); bad.use_urdf_inertia = 1
+    bad = c.copy(); bad.solver_residual_threshold = -1.0
     assert lib.solorl_create(C.byref(bad), 4, 0, 1, 0, C.byref(h)) == -1
     assert lib.solorl_dims(None, None, None, None) == -1
     if not torch.cuda.is_available():

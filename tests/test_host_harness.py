@@ -13,9 +13,11 @@ from tests.util import clone, state_vec, load_state
 from tests.golden.make_golden import stand_cfg, stand_action
 
 
-@pytest.mark.parametrize("robot,n", [(ROBOT_SOLO8, 8), (ROBOT_SOLO12, 12)])
-def test_free_flight_matches_dense_dynamics(robot, n):
-    c = default_config(robot, TASK_WALK)
+@pytest.mark.parametrize("robot,n,urdf_inertia", [(ROBOT_SOLO8, 8, 0), (ROBOT_SOLO12, 12, 0), (ROBOT_SOLO8, 8, 1), (ROBOT_SOLO12, 12, 1)])
+def test_free_flight_matches_dense_dynamics(robot, n, urdf_inertia):
+    """urdf_inertia = 1: SURVEY K2's other branch -- the URDF tensors with their products of inertia (ixy on the shoulders,
+    iyz on the upper and lower legs, signs mirrored left/right) instead of Bullet's default box rule."""
+    c = default_config(robot, TASK_WALK); c.use_urdf_inertia = urdf_inertia
     rng = np.random.default_rng(0)
     for trial in range(5):
         o = Oracle(c, 1)
@@ -29,8 +31,9 @@ def test_free_flight_matches_dense_dynamics(robot, n):
         assert np.abs(state_vec(o.get_state(0), n) - state_vec(h, n)).max() < 1e-11
 
 
-@pytest.mark.parametrize("robot,n,treadmill", [(ROBOT_SOLO8, 8, 0), (ROBOT_SOLO12, 12, 0), (ROBOT_SOLO8, 8, 1), (ROBOT_SOLO12, 12, 1)])
-def test_contact_substeps_resynced(robot, n, treadmill):
+@pytest.mark.parametrize("robot,n,treadmill,urdf_inertia", [(ROBOT_SOLO8, 8, 0, 0), (ROBOT_SOLO12, 12, 0, 0), (ROBOT_SOLO8, 8, 1, 0),
+                                                            (ROBOT_SOLO12, 12, 1, 0), (ROBOT_SOLO12, 12, 0, 1)])
+def test_contact_substeps_resynced(robot, n, treadmill, urdf_inertia):
     """Drop, land and thrash under random torques; every sub-step starts from the oracle's state.
     The contact sets must be identical.  Errors are judged statistically: Bullet-style PGS with
     mu = 1 box friction is a non-convergent fixed-point iteration in some multi-contact states
@@ -38,6 +41,7 @@ def test_contact_substeps_resynced(robot, n, treadmill):
     amplify rounding by many orders of magnitude in BOTH implementations."""
     c = default_config(robot, TASK_WALK)
     c.use_treadmill = treadmill        # strip under the left feet: per-contact friction 0.5, strip bits in the mask
+    c.use_urdf_inertia = urdf_inertia
     rng = np.random.default_rng(1)
     o = Oracle(c, 1)
     if treadmill:

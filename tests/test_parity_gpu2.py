@@ -400,3 +400,38 @@ def test_residual_threshold_early_exit_vs_oracle(gpu_device, team):
     assert np.median(its) < 20 and (its < 50).mean() > 0.6
     assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 2e-3, (np.median(dq), np.percentile(dq, 90))
     assert mism <= 0.02 * len(dq)
+
+
+# ------------------------------------------------------------------------------------------------ K2: URDF inertia
+@pytest.mark.parametrize("robot", [ROBOT_SOLO8, ROBOT_SOLO12])
+def test_urdf_inertia_vs_oracle(gpu_device, robot):
+    """use_urdf_inertia = 1 (SURVEY Appendix B K2 "implement both"): the URDF tensors incl. their products of inertia, whose
+    signs mirror left/right, in the team-mode leg phase (per-lane sign patterns) -- fp64 engine to rounding, fp32 engine to
+    the usual per-step bound; and it is a different robot from the box-inertia default."""
+    n = 8 if robot == ROBOT_SOLO8 else 12
+    outs = {}
+    for prec, tol in ((PRECISION_F64, 1e-10), (0, 1e-4)):
+        c = cfg_for(robot, TASK_WALK, use_urdf_inertia=1, precision=prec)
+        N = 32
+        env, orc = make(c, N, seed=4)
+        og = env.reset().cpu().numpy().astype(np.float64); oo = orc.reset()
+        assert obs_diff(og, oo, c.state_dim).max() < 2e-3
+        rng = np.random.default_rng(2)
+        errs = []
+        for t in range(12):
+            resync(orc, env, N)
+            a = (0.4 * rng.uniform(-1, 1, size=(N, n))).astype(np.float32)
+            _, _, d, _ = env.step(torch.from_numpy(a).cuda()); _, _, od, _ = orc.step(a.astype(np.float64))
+            d = d.cpu().numpy()
+            for i in range(N):
+                if not (d[i] or od[i]):
+                    errs.append(np.abs(np.array(env.get_state(i).q) - np.array(orc.get_state(i).q)).max())
+        assert np.median(errs) < tol, (prec, np.median(errs))
+        outs[prec] = np.array(env.get_state(0).q)
+    c0 = cfg_for(robot, TASK_WALK, precision=PRECISION_F64)
+    env0, _ = make(c0, 4, seed=4)
+    env0.reset()
+    rng = np.random.default_rng(2)
+    for t in range(12):
+        env0.step(torch.from_numpy((0.4 * rng.uniform(-1, 1, size=(32, n))).astype(np.float32)[:4]).cuda())
+    assert np.abs(np.array(env0.get_state(0).q) - outs[PRECISION_F64]).max() > 1e-4      # the inertia model matters
