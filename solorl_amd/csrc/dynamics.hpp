@@ -1395,11 +1395,18 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   auto elem = [&](int r, int e) -> T {                // element e of parked row r
     return *reinterpret_cast<const T*>(solo_smem + ((unsigned)((r * LDS::NCH + e / LDS::PER) * LN + col) * 16u + (unsigned)(e % LDS::PER) * SZ));
   };
-  // all arrays below are indexed by the sweep index i
-  T J0[n], J1[n], J2[n], B0[n], B1[n], B2[n], X0[n], X1[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
+  // all arrays below are indexed by the sweep index i.  The B~ / X~ columns of accumulator components 0 and 1 are kept as
+  // explicit 2-vectors (v_pk_fma_f32 on fp32; the translation unit is built with -fno-slp-vectorize, so what is packed
+  // is exactly what is written here -- left to itself the vectoriser paired unrelated multiplies of the slot's dependency
+  // chain and split its fused multiply-adds).  Per slot: 3 fma + 3 DPP adds (next slot's J'.acc), 2 fma + 1 sub + clamp + sub
+  // + swap + fma + clamp + sub + swap (the row pair), 2 packed + 2 scalar fma (accumulators) = 21-22 VALU instructions.
+  using P2 = T __attribute__((ext_vector_type(2)));
+  auto fm = [](auto a, auto b, auto c) { return __builtin_elementwise_fma(a, b, c); };
+  T J0[n], J1[n], J2[n], B2[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
+  P2 B01[n], X01[n];
   T th[EXIT ? n : 1];                            // (K7) |delta| above which a row keeps its team iterating
   T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
-  T a0 = T(0), a1 = T(0), a2 = T(0);
+  P2 a01 = {T(0), T(0)}; T a2 = T(0);
   static_for<n>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int k = Ord::slot(i);
@@ -1411,27 +1418,31 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     const T ju = elem(ro, eU), bu = elem(ro, eU + dJB), jv = elem(ro, eV), bv = elem(ro, eV + dJB), jw = elem(ro, eW), bw = elem(ro, eW + dJB);
     const T xu = elem(rx, eU + dJB), xv = elem(rx, eV + dJB), xw = elem(rx, eW + dJB);
     const T rhs = elem(ro, E_RHS);
-    J0[i] = uo ? ju : T(0); B0[i] = uo ? bu : T(0); J1[i] = vo ? jv : T(0); B1[i] = vo ? bv : T(0); J2[i] = wo ? jw : T(0); B2[i] = wo ? bw : T(0);
-    X0[i] = ux ? xu : T(0); X1[i] = vx ? xv : T(0); X2[i] = wx ? xw : T(0);
-    rh[i] = r_own >= 0 ? rhs : T(0);
+    J0[i] = uo ? ju : T(0); J1[i] = vo ? jv : T(0); J2[i] = wo ? jw : T(0);
+    B01[i] = P2{uo ? bu : T(0), vo ? bv : T(0)}; B2[i] = wo ? bw : T(0);
+    X01[i] = P2{ux ? xu : T(0), vx ? xv : T(0)}; X2[i] = wx ? xw : T(0);
+    // rhs' rides in the reduction: every lane of a half starts its partial sum at -rhs'/8 (exact scaling), so the reduced
+    // value is J'.acc - rhs' and the row update needs one subtraction instead of an add and a subtract
+    rh[i] = r_own >= 0 ? rhs * T(-0.125) : T(0);
     if constexpr (EXIT) th[i] = r_own >= 0 ? lds.A(ro, LDS::A_LAM) : T(0);
     // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
     // partner's B~; half 0 takes 0 (its row does not wait for anybody)
-    const T c = team_red8(J0[i] * X0[i] + J1[i] * X1[i] + J2[i] * X2[i]);
+    const T c = team_red8(J0[i] * X01[i].x + J1[i] * X01[i].y + J2[i] * X2[i]);
     cp[i] = half ? c : T(0);
     lm[i] = *reinterpret_cast<const T*>(solo_smem + lam_own + 2 * k * S_LAM);
     // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
     const T lx_ = half_swap(lm[i]);
     if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx_;
-    a0 += B0[i] * lm[i] + X0[i] * lx_; a1 += B1[i] * lm[i] + X1[i] * lx_; a2 += B2[i] * lm[i] + X2[i] * lx_;
+    a01 = fm(X01[i], P2{lx_, lx_}, fm(B01[i], P2{lm[i], lm[i]}, a01)); a2 = fm(X2[i], lx_, fm(B2[i], lm[i], a2));
   });
   // couplings with the predecessor slot (wrapping around: the first slot follows the last one of the previous sweep)
   static_for<n>([&](auto ic) {
     constexpr int i = decltype(ic)::value, p = (i + n - 1) % n;
-    eo[i] = team_red8(J0[i] * B0[p] + J1[i] * B1[p] + J2[i] * B2[p]);
-    ex[i] = team_red8(J0[i] * X0[p] + J1[i] * X1[p] + J2[i] * X2[p]);
+    eo[i] = team_red8(J0[i] * B01[p].x + J1[i] * B01[p].y + J2[i] * B2[p]);
+    ex[i] = team_red8(J0[i] * X01[p].x + J1[i] * X01[p].y + J2[i] * X2[p]);
   });
-  T dpre = team_red8(J0[0] * a0 + J1[0] * a1 + J2[0] * a2);
+  auto jdot = [&](int, T j0, T j1, T j2, T r8) -> T { return team_red8(fm(j0, a01.x, fm(j1, a01.y, fm(j2, a2, r8)))); };   // J'.acc - rhs'
+  T dpre = jdot(0, J0[0], J1[0], J2[0], rh[0]);
   T delp = T(0), delxp = T(0);
   // impulses and accumulators back to LDS for the leader (half 0 holds the same accumulators as half 1)
   T* const hdr = lds.hdr();
@@ -1443,8 +1454,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       }); \
     } \
     if (half == 0) { \
-      if (h < 6) hdr[(2 + h) * LN] = a0; else lds.y()[(h - 6) * LN] = a0; \
-      lds.y()[(h + 2) * LN] = a1; \
+      if (h < 6) hdr[(2 + h) * LN] = a01.x; else lds.y()[(h - 6) * LN] = a01.x; \
+      lds.y()[(h + 2) * LN] = a01.y; \
       if (h < 2) lds.y()[(10 + h) * LN] = a2; \
     } } while (0)
   // K7 early exit, per env as in the reference (one Bullet world per env): a team whose sweep changed no row by more
@@ -1459,11 +1470,11 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       constexpr int i = decltype(ic)::value, in = (i + 1) % n;
       constexpr bool fric = i >= LIM + NNS;
       // next slot's reduction on the accumulators as they are now (without this slot's update)
-      const T dnext = team_red8(J0[in] * a0 + J1[in] * a1 + J2[in] * a2);
+      const T dnext = jdot(in, J0[in], J1[in], J2[in], rh[in]);
 #ifdef SOLO_PGS_NOPIPE    // dev check: plain in-order reduction
-      const T d = team_red8(J0[i] * a0 + J1[i] * a1 + J2[i] * a2);
+      const T d = jdot(i, J0[i], J1[i], J2[i], rh[i]);
 #else
-      const T d = dpre + eo[i] * delp + ex[i] * delxp;
+      const T d = fm(ex[i], delxp, fm(eo[i], delp, dpre));
 #endif
       T hi = T(0);
       if constexpr (fric) {   // impulse of this contact's normal row: normal slot c/2, half c&1
@@ -1475,20 +1486,19 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
         else if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, -hi, hi);
         else return x < -hi ? -hi : (x > hi ? hi : x);
       };
-      T sp = (lm[i] + rh[i]) - d;
+      T sp = lm[i] - d;
       // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
       // (cp = 0 in half 0, whose second clamp therefore repeats the first)
       const T dfirst = clampb(sp) - lm[i];
-      sp -= cp[i] * half_swap(dfirst);
+      sp = fm(-cp[i], half_swap(dfirst), sp);
       const T sv = clampb(sp);
       const T del = sv - lm[i];
       if constexpr (EXIT) viol = viol || (fabs(del) > th[i]);
       lm[i] = sv;
       const T delx = half_swap(del);
       if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] += delx;
-      a0 += B0[i] * del + X0[i] * delx;
-      a1 += B1[i] * del + X1[i] * delx;
-      a2 += B2[i] * del + X2[i] * delx;
+      a01 = fm(X01[i], P2{delx, delx}, fm(B01[i], P2{del, del}, a01));
+      a2 = fm(X2[i], delx, fm(B2[i], del, a2));
       dpre = dnext; delp = del; delxp = delx;
     });
     if constexpr (EXIT) {

@@ -267,8 +267,15 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   const long long kstart_ = clock64();
 #endif
 #ifdef SOLO_WAVE_TIMING
-  const long long wt0_ = clock64(), wr0_ = wall_clock64();
-  long long wt1_ = 0, wt2_ = 0;
+  // stamps: 0 start, 1 env loaded, 2 torques, 3 history pushed (sub-steps begin), 4 sub-steps done, 5 state back in registers,
+  // 6 reward / termination / outputs, 7 auto-reset, 8 observation state published, 9 state stored, 10 end
+  long long wts_[11];
+  for (int i_ = 0; i_ < 11; i_++) wts_[i_] = 0;
+  const long long wr0_ = wall_clock64();
+  wts_[0] = clock64();
+#define WT_STAMP(i) do { wts_[i] = clock64(); } while (0)
+#else
+#define WT_STAMP(i) do {} while (0)
 #endif
   const int t = TEAM ? (threadIdx.x & 15) : 0;
   const int col = TEAM ? (threadIdx.x >> 4) : threadIdx.x;
@@ -297,6 +304,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   Env<T, NQ> E;
   if (TEAM ? valid : true) env = (idx_t)si[(idx_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
   if (lead) load_env(E, sf, si, L, (idx_t)N, e);
+  WT_STAMP(1);
 
   // ---- A3 apply_action
   T tau[NQ], asq = T(0);
@@ -314,6 +322,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     if (mode != MODE_STEP) tau[j] = T(0);
   }
   }
+  WT_STAMP(2);
 
   // ---- A4 simulator_step: history push (pre-step state), frame_skip sub-steps
   // Team mode: the leader publishes the D state values through LDS (the `bc` block is free outside the sub-steps)
@@ -363,9 +372,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #ifdef SOLO_PHASE_TIMING
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
 #endif
-#ifdef SOLO_WAVE_TIMING
-    wt1_ = clock64();
-#endif
+    WT_STAMP(3);
     if (lead) { ch.get().ps = E.ps; ch.get().tmy = E.tmy; }
     TEAM_SYNC();
     // warm-start impulse cache: HBM -> LDS once per step (a global load/store per sub-step left a memory round
@@ -381,11 +388,10 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const int m = substep_team<T, ROBOT>(pp, sf + (idx_t)L.lam * N + e, (idx_t)N, lds, t, lead, valid);
       if (lead) E.mask = m;
     }
-#ifdef SOLO_WAVE_TIMING
-    wt2_ = clock64();
-#endif
+    WT_STAMP(4);
     if (lead) E.ps = ch.get().ps;
     if (valid) for (int p = t; p < NPRIM; p += 16) sf[(idx_t)(L.lam + p) * N + e] = ch.get().lamp[p];
+    WT_STAMP(5);
 #ifdef SOLO_PHASE_TIMING
     if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[8], (unsigned long long)(clock64() - kstart_));
 #endif
@@ -471,11 +477,13 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     }
   }
 
+  WT_STAMP(6);
   // ---- auto-reset (agents/ppo/envs.py:39) and observation
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[9], (unsigned long long)(clock64() - kstart_));
 #endif
   if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (idx_t)N, e, env, snf, sni, M, P);
+  WT_STAMP(7);
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[10], (unsigned long long)(clock64() - kstart_));
 #endif
@@ -489,10 +497,12 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     }
     team_obs = 1;
   } else write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, env, P.task, out.obs);   // (a reset rewrote the history: leader only)
+  WT_STAMP(8);
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[11], (unsigned long long)(clock64() - kstart_));
 #endif
   store_env(E, sf, si, L, (idx_t)N, e);
+  WT_STAMP(9);
 #ifdef SOLO_PHASE_TIMING
   if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[12], (unsigned long long)(clock64() - kstart_));
 #endif
@@ -522,10 +532,11 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 #ifdef SOLO_WAVE_TIMING
     __builtin_amdgcn_s_waitcnt(0);     // (vmcnt = lgkmcnt = 0: the stores above have left)
     if (threadIdx.x == 0 && blockIdx.x < solo::SOLO_WT_WAVES) {
-      const long long wt3_ = clock64();
+      wts_[10] = clock64();
       unsigned long long* w_ = solo::solo_wave_times[blockIdx.x];
-      w_[0] = (unsigned long long)(wt1_ - wt0_); w_[1] = (unsigned long long)(wt2_ - wt1_); w_[2] = (unsigned long long)(wt3_ - wt2_);
+      w_[0] = (unsigned long long)(wts_[3] - wts_[0]); w_[1] = (unsigned long long)(wts_[4] - wts_[3]); w_[2] = (unsigned long long)(wts_[10] - wts_[4]);
       w_[3] = (unsigned long long)(wall_clock64() - wr0_);
+      for (int i_ = 0; i_ < 10; i_++) w_[6 + i_] = (unsigned long long)(wts_[i_ + 1] > wts_[i_] && wts_[i_] ? wts_[i_ + 1] - wts_[i_] : 0);
     }
 #endif
   }

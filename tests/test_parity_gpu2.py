@@ -65,7 +65,7 @@ def test_config5_pd_path_resynced_vs_oracle(gpu_device):
         drew += list(np.abs(rew - orew)[ok]); dobs += list(obs_diff(obs.cpu().numpy(), oobs, c.state_dim)[ok].max(axis=1))
         if t == 49:
             assert done.sum() >= 0.4 * N                      # everybody still up times out at exactly episode_length = 50 (the others fell)
-            assert obs_diff(obs.cpu().numpy(), oobs, c.state_dim).max() < 2e-3     # post-reset observations
+            assert obs_diff(obs.cpu().numpy(), oobs, c.state_dim)[done != 0].max() < 2e-3     # post-reset observations of the envs that ended
     dq = np.array(dq)
     assert timeouts >= 0.4 * N
     assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 6e-3, (np.median(dq), np.percentile(dq, 90))

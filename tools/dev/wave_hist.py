@@ -24,7 +24,7 @@ a = torch.rand(64, N, 12, device="cuda:0", generator=g) * 2 - 1
 for t in range(450): env.step_inplace(a[t % 64])
 L = _native.lib()
 nw = ((N + 3) // 4 + 7) & ~7
-F = 6
+F = 16
 recs, wall = [], []
 buf = (C.c_ulonglong * (nw * F))()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -46,6 +46,11 @@ print("wavefront duration: mean %.1f us  median %.1f  p90 %.1f  p99 %.1f  slowes
 print("slowest / median wavefront = %.2f ; slowest / mean = %.2f" % (tot.max(axis=1).mean() / np.median(tot), tot.max(axis=1).mean() / tot.mean()))
 print("parts of a wavefront (mean): load + action + history push %.1f us, the %d sub-steps %.1f us, reward / termination / reset / observation / store %.1f us" % (
     us(R[:, :, 0].mean()), c.frame_skip, us(R[:, :, 1].mean()), us(R[:, :, 2].mean())))
+segs = ["load env", "torques", "history push", "sub-steps", "state back", "reward/termination/outputs", "auto-reset", "obs state", "store env", "obs write + tail"]
+print("intervals between stamps (us; mean over all wavefronts | over the slowest 1 %):")
+slow_ = tot >= np.percentile(tot, 99)
+for i, n_ in enumerate(segs):
+    print("  %-28s %7.2f | %7.2f" % (n_, us(R[:, :, 6 + i].mean()), us(R[:, :, 6 + i][slow_].mean())))
 bw = 10.0
 edges = np.arange(0, us(tot.max()) + bw, bw)
 h, _ = np.histogram(us(tot), bins=edges)
