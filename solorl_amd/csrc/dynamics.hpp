@@ -39,7 +39,7 @@ constexpr double DISC_EPS2 = 1e-12;
 // [1] the sub-steps, [2] last sub-step -> end, [3] whole kernel in s_memrealtime ticks (100 MHz), [4] sum over the sub-steps of
 // the slots the wave swept, [5] the maximum over the sub-steps of its largest contact count
 #if defined(SOLO_WAVE_TIMING) && !defined(SOLO_HOST_SHIM)
-constexpr int SOLO_WT_WAVES = 65536, SOLO_WT_FIELDS = 6;
+constexpr int SOLO_WT_WAVES = 65536, SOLO_WT_FIELDS = 16;    // [6..15]: the ten intervals between the kernel's stamps
 __device__ unsigned long long solo_wave_times[SOLO_WT_WAVES][SOLO_WT_FIELDS];
 #endif
 // dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
@@ -1470,10 +1470,11 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       constexpr int i = decltype(ic)::value, in = (i + 1) % n;
       constexpr bool fric = i >= LIM + NNS;
       // next slot's reduction on the accumulators as they are now (without this slot's update)
-      const T dnext = jdot(in, J0[in], J1[in], J2[in], rh[in]);
-#ifdef SOLO_PGS_NOPIPE    // dev check: plain in-order reduction
+#ifdef SOLO_PGS_NOPIPE    // plain in-order reduction: 3 instructions fewer per slot, a 6-operation longer dependency chain
+      const T dnext = T(0);
       const T d = jdot(i, J0[i], J1[i], J2[i], rh[i]);
 #else
+      const T dnext = jdot(in, J0[in], J1[in], J2[in], rh[in]);
       const T d = fm(ex[i], delxp, fm(eo[i], delp, dpre));
 #endif
       T hi = T(0);
