@@ -315,6 +315,10 @@ template <typename T, int ROBOT> struct SubCtx {
   SV<T> ub; T qds[NQ];
   SV<T> w; T y[4][3]; T lam_n[8];
   T lamp[NPRIM];                   // team mode: warm-start impulse cache, held in LDS across the sub-steps of a step
+  // team mode, env logic (solorl_hip.hip step_team): the env's scalars in HBM field order (goal 2, potential, progress, goals,
+  // env goals, reward-term sums 5, previous xy 2, treadmill centre line), its counters (timestep, contact mask, rng, snapshot
+  // slot of a reset, done flag) and the commanded torques -- loaded, updated and stored by all 16 lanes
+  T erec[14]; int irec[6]; T tau_base[NQ];
 };
 
 // Context handles: the phases take the context through a handle so that its address space survives the

@@ -544,6 +544,334 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
 
 
 
+
+// ---------------------------------------------------------------- team mode (default): the whole step on 16 lanes per env
+// sum over the 16 lanes of a team (every lane ends with the total)
+template <typename T> SD T team_sum16(T x) {
+  if constexpr (sizeof(T) == 4) {
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+  } else {
+    x += __shfl_xor(x, 1, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 8, 16);
+  }
+  return x;
+}
+enum { ER_GOAL = 0, ER_POT = 2, ER_PROG = 3, ER_GOALS = 4, ER_EGOALS = 5, ER_DR = 6, ER_XYPREV = 11, ER_TMY = 13, NER = 14 };   // SubCtx::erec
+enum { IR_TIMESTEP = 0, IR_MASK = 1, IR_RNG = 2, IR_SNAP = 3, IR_DONE = 4 };                                                  // SubCtx::irec
+template <typename T, int ROBOT> SD void env_from_lds(Env<T, Robot<ROBOT>::NQ>& E, const SubCtx<T, ROBOT>& C) {
+  E.ps = C.ps;
+  E.goal[0] = C.erec[ER_GOAL]; E.goal[1] = C.erec[ER_GOAL + 1]; E.pot = C.erec[ER_POT]; E.prog = C.erec[ER_PROG];
+  E.goals = C.erec[ER_GOALS]; E.egoals = C.erec[ER_EGOALS];
+#pragma unroll
+  for (int k = 0; k < 5; k++) E.dr[k] = C.erec[ER_DR + k];
+  E.xyprev[0] = C.erec[ER_XYPREV]; E.xyprev[1] = C.erec[ER_XYPREV + 1]; E.tmy = C.erec[ER_TMY];
+  E.timestep = C.irec[IR_TIMESTEP]; E.mask = C.irec[IR_MASK]; E.rng = C.irec[IR_RNG];
+}
+template <typename T, int ROBOT> SD void scalars_to_lds(const Env<T, Robot<ROBOT>::NQ>& E, SubCtx<T, ROBOT>& C) {
+  C.erec[ER_GOAL] = E.goal[0]; C.erec[ER_GOAL + 1] = E.goal[1]; C.erec[ER_POT] = E.pot; C.erec[ER_PROG] = E.prog;
+  C.erec[ER_GOALS] = E.goals; C.erec[ER_EGOALS] = E.egoals;
+#pragma unroll
+  for (int k = 0; k < 5; k++) C.erec[ER_DR + k] = E.dr[k];
+  C.erec[ER_XYPREV] = E.xyprev[0]; C.erec[ER_XYPREV + 1] = E.xyprev[1]; C.erec[ER_TMY] = E.tmy;
+  C.irec[IR_TIMESTEP] = E.timestep; C.irec[IR_MASK] = E.mask; C.irec[IR_RNG] = E.rng;
+}
+
+// One launch = SoloBaseEnv.step for every env, 16 lanes (one DPP row) per env, 4 envs per wavefront.  Everything on the
+// wavefront's critical path is spread over the team's lanes: the env's state travels HBM <-> LDS with all 16 lanes (4 loads
+// per lane instead of 61 on one), joint t's action, clip and PD torque are lane t's, history / observation / impulse cache /
+// snapshot reset are moved by all lanes; only the scalar env logic (euler angles, reward, termination, Philox draws) runs on
+// the team leader, on values it reads from LDS.  Nothing but the six history values a lane needs for the observation deltas
+// stays in registers across the sub-steps (the round-1 version kept the env there: 56 spilled VGPRs per wavefront and step,
+// 11 MB of scratch write-back per launch against 5.7 MB of algorithmic traffic).
+template <typename T, int ROBOT>
+SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
+                  const Layout& L, int N, const EnvParams& P, const PhysParams<T>& pp, const float* __restrict__ actions,
+                  const Outputs& out, int mode) {
+  using RB = Robot<ROBOT>;
+  constexpr int NQ = RB::NQ, NPS = 13 + 2 * NQ;
+  using LDS = RowLds<T, 4>;
+  using CH = typename TeamCtx<T, ROBOT, LDS>::type;
+  static_assert(sizeof(PhysState<T, NQ>) == NPS * sizeof(T), "PhysState is the HBM field order pos, quat, v, w, q, qd");
+#ifdef SOLO_WAVE_TIMING
+  long long wts_[11];
+  for (int i_ = 0; i_ < 11; i_++) wts_[i_] = 0;
+  const long long wr0_ = wall_clock64();
+  wts_[0] = clock64();
+#endif
+  const int t = threadIdx.x & 15, col = threadIdx.x >> 4;
+  // a workgroup touches only 16 B of each state field, so eight consecutive workgroups share every 128-B line; workgroup
+  // ids go round-robin over the 8 XCDs (each with its own L2), hence give every XCD one CONTIGUOUS eighth of the env range
+  // instead of every eighth workgroup (grid is a multiple of 8).
+  const unsigned blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  idx_t e = (idx_t)blk * 4 + col;
+  const bool valid = e < (idx_t)N;
+  if (!valid) e = (idx_t)N - 1;           // every lane stays alive for the wave-level exchanges
+  const bool lead = valid && t == 0;
+  const idx_t NN = (idx_t)N;
+  LDS lds; lds.lanes = 4; lds.lane = col;
+  // test hook (SOLORL_POISON_LDS=<word>, read at create): pre-fill the whole dynamic LDS.  Two runs with different fill words
+  // (NaN vs 0) must agree bitwise -- anything read before it is written in the launch breaks that
+  // (tests/test_parity_gpu.py::test_no_lds_read_before_write; this is how a lane hand-off race was found)
+  if (P.lds_poison_on) {
+    using TC = TeamCtx<T, ROBOT, LDS>;
+    unsigned* w = reinterpret_cast<unsigned*>(solo_smem);
+    for (unsigned k = threadIdx.x; k < TC::bytes / 4; k += 64) w[k] = P.lds_poison;
+    __syncthreads();
+  }
+  const CH ch{col};
+  SubCtx<T, ROBOT>& C = ch.get();
+  T* const psv = reinterpret_cast<T*>(&C.ps);
+  T* const stage = TeamRows<T, LDS>::bc(col);
+  idx_t env = 0;
+  // ---- the env's state, HBM -> LDS, all lanes (the state is stored by slot: slot e holds env `env`)
+  T a_t = T(0);
+  if (valid) {
+    env = (idx_t)si[(idx_t)I_ENVID * NN + e];
+    for (int f = t; f < NPS; f += 16) psv[f] = sf[(idx_t)(L.pos + f) * NN + e];
+    if (t < NER) C.erec[t] = sf[(idx_t)(L.goal + t) * NN + e];
+    if (t < 3) C.irec[t] = si[(idx_t)t * NN + e];
+    for (int p = t; p < NPRIM; p += 16) C.lamp[p] = sf[(idx_t)(L.lam + p) * NN + e];
+    if (t < NQ && mode == MODE_STEP) a_t = (T)actions[env * NQ + t];
+  }
+  static_assert(I_TIMESTEP == IR_TIMESTEP && I_MASK == IR_MASK && I_RNG == IR_RNG, "counter order");
+  TEAM_SYNC();
+  WT_STAMP(1);
+  // ---- A3 apply_action (solo.py:224-259, controllers/PD.py:3-10): joint t on lane t
+  if (valid && t < NQ) {
+    const T c = a_t < T(-1) ? T(-1) : (a_t > T(1) ? T(1) : a_t);
+    T tq;
+    if (P.control == SOLORL_CONTROL_TORQUE) tq = c * T(P.max_torque);
+    else tq = clampv(T(P.kp) * (c * pp.qlim - C.ps.q[t]) - T(P.kd) * C.ps.qd[t], T(P.max_torque));
+    C.tau_base[t] = mode == MODE_STEP ? tq : T(0);
+  }
+  const T asq = team_sum16(a_t * a_t);        // sum of the raw, unclipped action squares (baseEnv.py:142-144)
+  WT_STAMP(2);
+  // ---- A4 simulator_step: history push (pre-step state).  The leader publishes the D state values through LDS (the `bc`
+  // block is free outside the sub-steps) and lane t moves elements t, t+16, t+32 -- 64-B coalesced segments -- keeping what
+  // it wrote (hk0 = new newest = pre-step state, hk1 = old newest) for the observation at the end.
+  constexpr int HK = (DMAX + 15) / 16;
+  T hk0[HK], hk1[HK];
+#pragma unroll
+  for (int k = 0; k < HK; k++) { hk0[k] = T(0); hk1[k] = T(0); }
+  if (lead) {
+    if (L.H > 0) {
+      Env<T, NQ> E;
+      env_from_lds<T, ROBOT>(E, C);
+      T cs[DMAX];
+      current_state<T, ROBOT>(E, P.task, cs);
+#pragma unroll
+      for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
+    }
+    C.erec[ER_XYPREV] = C.ps.pos.x; C.erec[ER_XYPREV + 1] = C.ps.pos.y;
+    C.tmy = C.erec[ER_TMY];
+  }
+  TEAM_SYNC();
+  if (valid && L.H > 0) {
+#pragma unroll
+    for (int k = 0; k < HK; k++) {
+      const int d = t + 16 * k;
+      if (d < L.D) {
+        const T c = stage[d];
+        if (L.H == 2) { hk1[k] = sf[(idx_t)(L.hist + d) * NN + e]; sf[(idx_t)(L.hist + DMAX + d) * NN + e] = hk1[k]; }
+        sf[(idx_t)(L.hist + d) * NN + e] = c;
+        hk0[k] = c;
+      }
+    }
+  }
+  WT_STAMP(3);
+  // ---- frame_skip physics sub-steps
+#pragma unroll 1
+  for (int ss = 0; ss < P.frame_skip; ss++) {
+    const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
+    if (valid && t < NQ) C.tau[t] = C.tau_base[t] * sc;
+    const int m = substep_team<T, ROBOT>(pp, sf + (idx_t)L.lam * NN + e, NN, lds, t, lead, valid);
+    if (lead) C.irec[IR_MASK] = m;
+  }
+  WT_STAMP(4);
+  if (valid) for (int p = t; p < NPRIM; p += 16) sf[(idx_t)(L.lam + p) * NN + e] = C.lamp[p];
+  WT_STAMP(5);
+  // ---- scalar env logic on the leader (values from LDS)
+  if (lead) {
+    Env<T, NQ> E;
+    env_from_lds<T, ROBOT>(E, C);
+    int done = 0;
+    if (P.task == SOLORL_TASK_POINTGOAL && mode == MODE_STEP) {     // solo.py:266-272
+      T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
+      T np = sqrt(dx * dx + dy * dy);
+      E.prog = -(np - E.pot); E.pot = np;
+      if (np < T(0.5)) { E.goals += T(1); sample_goal(E, P, P.id0 + (long long)env); }
+    }
+    if (mode == MODE_STEP) {
+      E.timestep += 1;
+      // ---- A7 reward (baseEnv.py:91-157)
+      const T z = E.ps.pos.z;
+      T stand = z > T(0.2) ? T(0.5) : T(0), jp = T(0), balance = T(0), progress = T(0), torque = T(0);
+#pragma unroll
+      for (int j = 0; j < NQ; j++) jp += P.task == SOLORL_TASK_STAND ? fabs(E.ps.q[j]) : E.ps.q[j] * E.ps.q[j];
+      jp = T(-0.1) * jp / T(NQ);
+      if (P.task == SOLORL_TASK_WALK) {
+        if (z > T(0.2)) { T vx = E.ps.v.x; progress = T(2) * (vx > T(0) ? T(1) : (vx < T(0) ? T(-1) : T(0))) * vx * vx; }
+      } else if (P.task == SOLORL_TASK_POINTGOAL) {
+        T r, p, y; euler_zyx(E.ps.qx, E.ps.qy, E.ps.qz, E.ps.qw, r, p, y);
+        balance = T(-0.1) * (fabs(r) + fabs(p));
+        if (z > T(0.2)) progress = E.prog * T(1.0 / P.reward_dt);
+      }
+      if (P.control == SOLORL_CONTROL_TORQUE) torque = T(-0.01) * asq;
+      T reward = stand + jp + balance + progress + torque;
+      E.dr[0] += stand; E.dr[1] += jp; E.dr[2] += torque; E.dr[3] += balance; E.dr[4] += progress;
+      // ---- A8 termination (baseEnv.py:162-180) + NaN guard
+      int to = 0, su = 0, nanr = 0;
+      {
+        T chk = E.ps.pos.x + E.ps.pos.y + E.ps.pos.z + E.ps.qw + E.ps.v.x + E.ps.v.y + E.ps.v.z + E.ps.w.x + E.ps.w.y + E.ps.w.z;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) chk += E.ps.q[j] + E.ps.qd[j];
+        if (!(fabs(chk) < T(1e30))) { nanr = 1; done = 1; reward = T(0); }
+      }
+      if (!P.disable_termination && !nanr) {
+        if (E.timestep >= P.episode_length) { done = 1; to = 1; su = P.task != SOLORL_TASK_POINTGOAL; }
+        else if (z < T(0.05)) { done = 1; }
+        else if (P.task == SOLORL_TASK_POINTGOAL && E.goals > E.egoals) { E.egoals = E.goals; done = 1; su = 1; }
+      }
+      if (done && !nanr) {   // baseEnv.py:52-60
+        if (su) { if (P.task == SOLORL_TASK_POINTGOAL) reward = T(0.1) * T(P.episode_length - E.timestep); }
+        else if (!to) reward = T(-10);
+      }
+      out.rew[env] = (float)reward;
+      out.done[env] = (unsigned char)done;
+      if (out.timeout) out.timeout[env] = (unsigned char)to;
+      if (out.success) out.success[env] = (unsigned char)su;
+      if (out.nan_reset) out.nan_reset[env] = (unsigned char)nanr;
+      if (out.ep_len) out.ep_len[env] = E.timestep;
+      if (out.ep_rew) out.ep_rew[env] = (float)reward;
+      if (out.goals) out.goals[env] = (float)E.egoals;
+      if (out.dr0) out.dr0[env] = (float)E.dr[0];
+      if (out.dr1) out.dr1[env] = (float)E.dr[1];
+      if (out.dr2) out.dr2[env] = (float)E.dr[2];
+      if (out.dr3) out.dr3[env] = (float)E.dr[3];
+      if (out.dr4) out.dr4[env] = (float)E.dr[4];
+      if (done && out.ep_stats) {      // finished-episode accumulators, one column per env (agents/ppo/train.py:90-100)
+        float* s = out.ep_stats + env;
+        if (nanr) s[9 * NN] += 1.0f;
+        else {
+          s[0] += 1.0f; s[NN] += (float)reward; s[2 * NN] += (float)E.timestep; s[3 * NN] += (float)su;
+#pragma unroll
+          for (int k = 0; k < 5; k++) s[(4 + k) * NN] += (float)E.dr[k];
+        }
+      }
+      // ---- auto-reset (agents/ppo/envs.py:39 -> baseEnv.py:70-82), part 1: the draws, in the reference's order -- treadmill
+      // side (scene.reset inside robot.reset, solo.py:166-168), goal (robot.reset), settle count (env.reset)
+      if (done) {
+        const long long gid = P.id0 + (long long)env;
+        int side = 0;
+        if (P.use_treadmill) {
+          unsigned rt[4];
+          philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)E.rng++, 3u, rt);
+          side = (rt[0] & 1u) ? 0 : 1;               // 0: strip centred on +offset, 1: on -offset (second half of the snapshot table)
+        }
+        if (P.task == SOLORL_TASK_POINTGOAL) sample_goal(E, P, gid);
+        unsigned r[4];
+        philox(P.seed_lo, P.seed_hi, (unsigned)gid, (unsigned)((unsigned long long)gid >> 32), (unsigned)E.rng++, 2u, r);
+        C.irec[IR_SNAP] = (int)(r[0] % (unsigned)P.nsettle) + side * P.nsettle;
+      }
+    }
+    scalars_to_lds<T, ROBOT>(E, C);          // (a reset keeps the goal and the rng counter from here)
+    C.irec[IR_DONE] = done;
+  }
+  WT_STAMP(6);
+  TEAM_SYNC();
+  const int done = valid ? C.irec[IR_DONE] : 0;
+  if (done) {
+    // ---- auto-reset, part 2 = SoloBaseEnv.reset in O(1): the pre-simulated post-settle state (snapshot slot) replaces the env's
+    // state, every field moved by the team -- HBM for all of them, LDS too for what the rest of this step reads
+    const idx_t k = (idx_t)C.irec[IR_SNAP], MM = (idx_t)M;
+    for (int f = t; f < L.NF; f += 16) {
+      const T v = snf[(idx_t)f * MM + k];
+      const bool scalar = f >= L.goal && f < L.goal + NER;
+      if (!scalar) sf[(idx_t)f * NN + e] = v;                     // (the scalars are stored at the end, patched)
+      if (f < NPS) psv[f] = v;
+      else if (scalar && f != L.goal && f != L.goal + 1) C.erec[f - L.goal] = v;     // (the goal just drawn stays)
+    }
+    if (t == 1) C.irec[IR_MASK] = sni[(idx_t)I_MASK * MM + k];
+#pragma unroll
+    for (int kk = 0; kk < HK; kk++) {          // this lane's history elements, for the observation deltas
+      const int d = t + 16 * kk;
+      if (d < L.D) {
+        if (L.H >= 1) hk0[kk] = snf[(idx_t)(L.hist + d) * MM + k];
+        if (L.H == 2) hk1[kk] = snf[(idx_t)(L.hist + DMAX + d) * MM + k];
+      }
+    }
+    TEAM_SYNC();
+    const T g0 = C.erec[ER_GOAL], g1 = C.erec[ER_GOAL + 1];
+    if (P.task == SOLORL_TASK_POINTGOAL) {     // the history keeps the NEW goal (set before the settle steps, solo.py:170-176)
+#pragma unroll
+      for (int kk = 0; kk < HK; kk++) {
+        const int d = t + 16 * kk;
+        if (d == L.D - 2 || d == L.D - 1) {
+          const T gv = (d == L.D - 2 ? g0 : g1) * T(0.5);
+          if (L.H >= 1) { hk0[kk] = gv; sf[(idx_t)(L.hist + d) * NN + e] = gv; }
+          if (L.H == 2) { hk1[kk] = gv; sf[(idx_t)(L.hist + DMAX + d) * NN + e] = gv; }
+        }
+      }
+    }
+    if (t == 0) {
+      C.irec[IR_TIMESTEP] = 0;
+      C.erec[ER_GOALS] = T(0); C.erec[ER_EGOALS] = T(0);
+#pragma unroll
+      for (int q = 0; q < 5; q++) C.erec[ER_DR + q] = T(0);
+      if (P.task == SOLORL_TASK_POINTGOAL) {
+        const T dx = C.ps.pos.x - g0, dy = C.ps.pos.y - g1, px = C.erec[ER_XYPREV] - g0, py = C.erec[ER_XYPREV + 1] - g1;
+        const T pot = sqrt(dx * dx + dy * dy);
+        C.erec[ER_POT] = pot; C.erec[ER_PROG] = -(pot - sqrt(px * px + py * py));
+      }
+    }
+  }
+  WT_STAMP(7);
+  // ---- A6 observation (solo.py:186-196): [s, s - hist_newest, s - hist_older], element d on lane d mod 16
+  const bool want_obs = mode == MODE_STEP;
+  if (lead && want_obs) {
+    Env<T, NQ> E;
+    env_from_lds<T, ROBOT>(E, C);
+    T cs[DMAX];
+    current_state<T, ROBOT>(E, P.task, cs);
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
+  }
+  TEAM_SYNC();
+  WT_STAMP(8);
+  if (valid) {
+    if (want_obs) {
+      float* o = out.obs + env * (idx_t)(L.D * (1 + L.H));
+#pragma unroll
+      for (int k = 0; k < HK; k++) {
+        const int d = t + 16 * k;
+        if (d < L.D) {
+          const T c = stage[d];
+          o[d] = (float)c;
+          if (L.H >= 1) o[L.D + d] = (float)(c - hk0[k]);
+          if (L.H == 2) o[2 * L.D + d] = (float)(c - hk1[k]);
+        }
+      }
+    }
+    // ---- the env's state, LDS -> HBM, all lanes
+    for (int f = t; f < NPS; f += 16) sf[(idx_t)(L.pos + f) * NN + e] = psv[f];
+    if (t < NER) sf[(idx_t)(L.goal + t) * NN + e] = C.erec[t];
+    if (t < 3) si[(idx_t)t * NN + e] = C.irec[t];
+  }
+  WT_STAMP(9);
+#ifdef SOLO_WAVE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);     // (vmcnt = lgkmcnt = 0: the stores above have left)
+  if (threadIdx.x == 0 && blockIdx.x < solo::SOLO_WT_WAVES) {
+    wts_[10] = clock64();
+    unsigned long long* w_ = solo::solo_wave_times[blockIdx.x];
+    w_[0] = (unsigned long long)(wts_[3] - wts_[0]); w_[1] = (unsigned long long)(wts_[4] - wts_[3]); w_[2] = (unsigned long long)(wts_[10] - wts_[4]);
+    w_[3] = (unsigned long long)(wall_clock64() - wr0_);
+    for (int i_ = 0; i_ < 10; i_++) w_[6 + i_] = (unsigned long long)(wts_[i_ + 1] > wts_[i_] && wts_[i_] ? wts_[i_ + 1] - wts_[i_] : 0);
+  }
+#endif
+}
+
 template <typename T, int ROBOT>
 __global__ void __launch_bounds__(64)
 step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
@@ -562,7 +890,7 @@ template <typename T, int ROBOT>
 __global__ void __launch_bounds__(64, SOLO_WAVES_PER_SIMD)
 step_kernel_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
                  Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
-  step_body<T, ROBOT, true>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
+  step_team<T, ROBOT>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
 }
 
 template <typename T, int ROBOT>
