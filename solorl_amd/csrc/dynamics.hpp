@@ -42,20 +42,6 @@ constexpr double DISC_EPS2 = 1e-12;
 constexpr int SOLO_WT_WAVES = 65536, SOLO_WT_FIELDS = 16;    // [6..15]: the ten intervals between the kernel's stamps
 __device__ unsigned long long solo_wave_times[SOLO_WT_WAVES][SOLO_WT_FIELDS];
 #endif
-// dev builds (-DSOLO_PHASE_TIMING, tools/dev/phase_timing.py): cycles per phase, summed over all waves
-#if defined(SOLO_PHASE_TIMING) && !defined(SOLO_HOST_SHIM)
-__device__ unsigned long long solo_phase_cycles[48];
-// per-wavefront records of ONE launch (tools/dev/wave_hist.py zeroes them before it): [workgroup][0..6] cycles per phase
-// (index as solo_phase_cycles), [8] whole kernel, [9] sum over the sub-steps of the wave's largest contact count, [10] its maximum
-constexpr int SOLO_WREC_WAVES = 16384, SOLO_WREC_FIELDS = 12;
-__device__ unsigned long long solo_wave_rec[SOLO_WREC_WAVES][SOLO_WREC_FIELDS];
-#define SOLO_TICK(i) do { const long long now_ = clock64(); if (threadIdx.x == 0) { atomicAdd(&solo_phase_cycles[i], (unsigned long long)(now_ - tick_)); \
-    if (blockIdx.x < SOLO_WREC_WAVES) solo_wave_rec[blockIdx.x][i] += (unsigned long long)(now_ - tick_); } tick_ = clock64(); } while (0)
-#define SOLO_TICK_INIT long long tick_ = clock64()
-#else
-#define SOLO_TICK(i) do {} while (0)
-#define SOLO_TICK_INIT do {} while (0)
-#endif
 
 template <int N, typename F, int... I>
 SD void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -1525,17 +1511,11 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
 #undef SOLO_PGS_WRITE_BACK
 }
 
-#ifdef SOLO_PHASE_TIMING
-__device__ unsigned long long solo_pgs_cycles[2][10];     // [cycles | calls][wave's largest contact count]
-#endif
 template <typename T, int ROBOT, typename LDS>
 SD void phase_pgs_team(int iterations, bool early_exit, const LDS lds, int t) {
   constexpr int LN = LDS::LANES;
   int nlt, nc, ncmax, anylim;
   team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
-#ifdef SOLO_PHASE_TIMING
-  const long long pgs_t0_ = clock64();
-#endif
 #if defined(SOLO_WAVE_TIMING)
   if (threadIdx.x == 0 && blockIdx.x < SOLO_WT_WAVES) {
     solo_wave_times[blockIdx.x][4] += (unsigned long long)(ncmax + (ncmax + 1) / 2 + (anylim ? 1 : 0));   // slots swept
@@ -1569,16 +1549,6 @@ SD void phase_pgs_team(int iterations, bool early_exit, const LDS lds, int t) {
     default: SOLO_SWEEP_L(4, 8); break;
   }
 #undef SOLO_SWEEP_L
-#ifdef SOLO_PHASE_TIMING
-  if (threadIdx.x == 0) {
-    atomicAdd(&solo_pgs_cycles[0][ncmax], (unsigned long long)(clock64() - pgs_t0_));
-    atomicAdd(&solo_pgs_cycles[1][ncmax], 1ull);
-    if (blockIdx.x < SOLO_WREC_WAVES) {
-      solo_wave_rec[blockIdx.x][9] += (unsigned long long)ncmax;
-      if ((unsigned long long)ncmax > solo_wave_rec[blockIdx.x][10]) solo_wave_rec[blockIdx.x][10] = (unsigned long long)ncmax;
-    }
-  }
-#endif
 }
 
 // apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.
@@ -1638,7 +1608,6 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   using TRW = TeamRows<T, LDS>;
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
   const CH ch{lds.lane};
-  SOLO_TICK_INIT;
   if (valid && t < Robot<ROBOT>::NQ) {   // sin/cos of joint t on lane t
     SubCtx<T, ROBOT>& C = ch.get();
     T sn, cs;
@@ -1651,7 +1620,6 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
 #ifdef SOLO_DUP_FRONT      // dev: run an idempotent phase twice -- the launch-time delta is that phase's true cost
   phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
 #endif
-  SOLO_TICK(0);
   if (valid && t < 4) {                                                                     // four legs on four lanes
     if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t);
     else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
@@ -1659,7 +1627,6 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
 #ifdef SOLO_DUP_LEGS
   if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
 #endif
-  SOLO_TICK(1);
   if (valid) team_sum_base<T, ROBOT, CH>(ch, t);
 #ifdef SOLO_DUP_BASE       // dev timing (tools/dev/dup_phase.sh); idempotent now that the leg sum is a separate step
   if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
@@ -1669,16 +1636,12 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
   if (valid) phase_legrates_team<T, ROBOT, LDS, CH>(ch, pp, lds, t);
-  SOLO_TICK(2);
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #ifdef SOLO_DUP_FINISH
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #endif
-  SOLO_TICK(3);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.resid_thr >= T(0), lds, t);
-  SOLO_TICK(5);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
-  SOLO_TICK(6);
   return lead ? (ch.get().mask | strip_feet_bits(ch.get().smask)) : 0;
 }
 #endif  // !SOLO_HOST_SHIM

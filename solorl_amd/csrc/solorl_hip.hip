@@ -219,14 +219,7 @@ SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L,
 template <typename T, int ROBOT>
 SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& L, idx_t N, idx_t e, idx_t env, int task, float* obs) {
   T cs[DMAX];
-#ifdef SOLO_PHASE_TIMING
-  long long wt_ = clock64();
-#define WOBS_TICK(i) do { const long long n_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&solo::solo_phase_cycles[i], (unsigned long long)(n_ - wt_)); wt_ = clock64(); } while (0)
-#else
-#define WOBS_TICK(i) do {} while (0)
-#endif
   current_state<T, ROBOT>(E, task, cs);
-  WOBS_TICK(13);
   const int O = L.D * (1 + L.H);
   float* o = obs + env * (idx_t)O;
   // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older].  All history loads are issued
@@ -237,7 +230,6 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
   for (int h = 0; h < 2; h++)
 #pragma unroll
     for (int d = 0; d < DMAX; d++) hv[h][d] = (h < L.H && d < L.D) ? sf[(idx_t)(L.hist + h * DMAX + d) * N + e] : T(0);
-  WOBS_TICK(14);
 #pragma unroll
   for (int d = 0; d < DMAX; d++)
     if (d < L.D) {
@@ -246,69 +238,29 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
       for (int h = 0; h < 2; h++)
         if (h < L.H) o[(h + 1) * L.D + d] = (float)(cs[d] - hv[h][d]);
     }
-  WOBS_TICK(15);
 }
 
-// ---------------------------------------------------------------- the hot kernel
-// TEAM = true  (team mode, default): 16 lanes per env, 4 envs per wavefront.  The team leader (t == 0) runs the env
-//   logic; history / observation / impulse cache are moved by all 16 lanes; the sub-steps are substep_team
-//   (dynamics.hpp).  With 4096 envs there is one wavefront per SIMD and the launch lasts as long as its heaviest
-//   wave, so everything on that wave's critical path is spread over the team's lanes.
-// TEAM = false (lane mode, SOLORL_TEAM=0): one env per lane, 64 envs per wavefront.
-template <typename T, int ROBOT, bool TEAM>
+// ---------------------------------------------------------------- lane mode (SOLORL_TEAM=0): one env per lane
+// 64 envs per wavefront, the env in registers, rows in LDS.  Kept as an independent second implementation of the same
+// step (GPU test: lane vs team vs sorted storage agree); the default is step_team below.
+template <typename T, int ROBOT>
 SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
                   const Layout& L, int N, const EnvParams& P, const PhysParams<T>& pp, const float* __restrict__ actions,
                   const Outputs& out, int mode) {
   using RB = Robot<ROBOT>;
   constexpr int NQ = RB::NQ;
-  using LDS = typename std::conditional<TEAM, RowLds<T, 4>, RowLds<T>>::type;
+  using LDS = RowLds<T>;
   constexpr int EPB = LDS::LANES;          // envs per workgroup: compile-time (LDS immediates)
-#ifdef SOLO_PHASE_TIMING
-  const long long kstart_ = clock64();
-#endif
-#ifdef SOLO_WAVE_TIMING
-  // stamps: 0 start, 1 env loaded, 2 torques, 3 history pushed (sub-steps begin), 4 sub-steps done, 5 state back in registers,
-  // 6 reward / termination / outputs, 7 auto-reset, 8 observation state published, 9 state stored, 10 end
-  long long wts_[11];
-  for (int i_ = 0; i_ < 11; i_++) wts_[i_] = 0;
-  const long long wr0_ = wall_clock64();
-  wts_[0] = clock64();
-#define WT_STAMP(i) do { wts_[i] = clock64(); } while (0)
-#else
-#define WT_STAMP(i) do {} while (0)
-#endif
-  const int t = TEAM ? (threadIdx.x & 15) : 0;
-  const int col = TEAM ? (threadIdx.x >> 4) : threadIdx.x;
-  // team mode: a workgroup touches only 16 B of each state field, so eight consecutive workgroups share every
-  // 128-B line; workgroup ids go round-robin over the 8 XCDs (each with its own L2), hence give every XCD one
-  // CONTIGUOUS eighth of the env range instead of every eighth workgroup (grid is a multiple of 8).
-  const unsigned blk = TEAM ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  idx_t e = (idx_t)blk * EPB + col;
-  const bool valid = e < (idx_t)N;
-  if (!TEAM && !valid) return;
-  if (!valid) e = (idx_t)N - 1;           // team mode keeps every lane alive for the wave-level exchanges
-  const bool lead = valid && t == 0;
+  const int col = threadIdx.x;
+  idx_t e = (idx_t)blockIdx.x * EPB + col;
+  if (e >= (idx_t)N) return;
   LDS lds; lds.lanes = EPB; lds.lane = col;
-  if constexpr (TEAM) {
-    // test hook (SOLORL_POISON_LDS=<word>, read at create): pre-fill the whole dynamic LDS.  Two runs with different
-    // fill words (NaN vs 0) must agree bitwise -- anything read before it is written in the launch breaks that
-    // (tests/test_parity_gpu.py::test_no_lds_read_before_write; this is how a lane hand-off race was found)
-    if (P.lds_poison_on) {
-      using TC = TeamCtx<T, ROBOT, LDS>;
-      unsigned* w = reinterpret_cast<unsigned*>(solo_smem);
-      for (unsigned k = threadIdx.x; k < TC::bytes / 4; k += 64) w[k] = P.lds_poison;
-      __syncthreads();
-    }
-  }
-  idx_t env = 0;
   Env<T, NQ> E;
-  if (TEAM ? valid : true) env = (idx_t)si[(idx_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
-  if (lead) load_env(E, sf, si, L, (idx_t)N, e);
-  WT_STAMP(1);
+  const idx_t env = (idx_t)si[(idx_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
+  load_env(E, sf, si, L, (idx_t)N, e);
 
   // ---- A3 apply_action
   T tau[NQ], asq = T(0);
-  if (lead) {
 #pragma unroll
   for (int j = 0; j < NQ; j++) {
     T a = mode == MODE_STEP ? (T)actions[env * NQ + j] : T(0);
@@ -321,39 +273,9 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     }
     if (mode != MODE_STEP) tau[j] = T(0);
   }
-  }
-  WT_STAMP(2);
 
   // ---- A4 simulator_step: history push (pre-step state), frame_skip sub-steps
-  // Team mode: the leader publishes the D state values through LDS (the `bc` block is free outside the sub-steps)
-  // and lane t moves elements t, t+16, t+32 -- 64-B coalesced segments, 3 instead of 38 load/store rounds -- and
-  // keeps what it wrote (hk0 = new newest = pre-step state, hk1 = old newest) for the observation at the end.
-  constexpr int HK = (DMAX + 15) / 16;
-  T hk0[HK], hk1[HK];
-#pragma unroll
-  for (int k = 0; k < HK; k++) { hk0[k] = T(0); hk1[k] = T(0); }
-  if constexpr (TEAM) {
-    T* stage = TeamRows<T, LDS>::bc(col);
-    if (lead && L.H > 0) {
-      T cs[DMAX];
-      current_state<T, ROBOT>(E, P.task, cs);
-#pragma unroll
-      for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
-    }
-    TEAM_SYNC();
-    if (valid && L.H > 0) {
-#pragma unroll
-      for (int k = 0; k < HK; k++) {
-        const int d = t + 16 * k;
-        if (d < L.D) {
-          const T c = stage[d];
-          if (L.H == 2) { hk1[k] = sf[(idx_t)(L.hist + d) * N + e]; sf[(idx_t)(L.hist + DMAX + d) * N + e] = hk1[k]; }
-          sf[(idx_t)(L.hist + d) * N + e] = c;
-          hk0[k] = c;
-        }
-      }
-    }
-  } else if (L.H > 0) {
+  if (L.H > 0) {
     T cs[DMAX], h0[DMAX];
     current_state<T, ROBOT>(E, P.task, cs);
 #pragma unroll
@@ -366,36 +288,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       }
   }
   E.xyprev[0] = E.ps.pos.x; E.xyprev[1] = E.ps.pos.y;
-  if constexpr (TEAM) {
-    using CH = typename TeamCtx<T, ROBOT, LDS>::type;
-    const CH ch{col};
-#ifdef SOLO_PHASE_TIMING
-    if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[7], (unsigned long long)(clock64() - kstart_));
-#endif
-    WT_STAMP(3);
-    if (lead) { ch.get().ps = E.ps; ch.get().tmy = E.tmy; }
-    TEAM_SYNC();
-    // warm-start impulse cache: HBM -> LDS once per step (a global load/store per sub-step left a memory round
-    // trip exposed at every phase boundary: the non-inlined calls wait for all outstanding VMEM)
-    if (valid) for (int p = t; p < NPRIM; p += 16) ch.get().lamp[p] = sf[(idx_t)(L.lam + p) * N + e];
-#pragma unroll 1
-    for (int ss = 0; ss < P.frame_skip; ss++) {
-      const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
-      if (lead) {
-#pragma unroll
-        for (int j = 0; j < NQ; j++) ch.get().tau[j] = tau[j] * sc;
-      }
-      const int m = substep_team<T, ROBOT>(pp, sf + (idx_t)L.lam * N + e, (idx_t)N, lds, t, lead, valid);
-      if (lead) E.mask = m;
-    }
-    WT_STAMP(4);
-    if (lead) E.ps = ch.get().ps;
-    if (valid) for (int p = t; p < NPRIM; p += 16) sf[(idx_t)(L.lam + p) * N + e] = ch.get().lamp[p];
-    WT_STAMP(5);
-#ifdef SOLO_PHASE_TIMING
-    if (threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[8], (unsigned long long)(clock64() - kstart_));
-#endif
-  } else {
+  {
     SubCtx<T, ROBOT> C;
     C.ps = E.ps; C.tmy = E.tmy;
 #pragma unroll 1
@@ -407,16 +300,13 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     }
     E.ps = C.ps;
   }
-  int team_obs = 0;          // team mode: 1 = the lanes write the observation together (the env did not reset)
-  if (lead) {
   if (P.task == SOLORL_TASK_POINTGOAL && mode == MODE_STEP) {
     T dx = E.ps.pos.x - E.goal[0], dy = E.ps.pos.y - E.goal[1];
     T np = sqrt(dx * dx + dy * dy);
     E.prog = -(np - E.pot); E.pot = np;
     if (np < T(0.5)) { E.goals += T(1); sample_goal(E, P, P.id0 + (long long)env); }
   }
-  if (mode == MODE_SETTLE) store_env(E, sf, si, L, (idx_t)N, e);
-  else {
+  if (mode == MODE_SETTLE) { store_env(E, sf, si, L, (idx_t)N, e); return; }
   E.timestep += 1;
 
   // ---- A7 reward (baseEnv.py:91-157)
@@ -477,73 +367,17 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     }
   }
 
-  WT_STAMP(6);
   // ---- auto-reset (agents/ppo/envs.py:39) and observation
-#ifdef SOLO_PHASE_TIMING
-  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[9], (unsigned long long)(clock64() - kstart_));
-#endif
   if (done) reset_from_snapshot<T, ROBOT>(E, sf, L, (idx_t)N, e, env, snf, sni, M, P);
-  WT_STAMP(7);
-#ifdef SOLO_PHASE_TIMING
-  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[10], (unsigned long long)(clock64() - kstart_));
-#endif
-  if (TEAM && !done) {        // publish the new state values; all 16 lanes write the observation below
-    T cs[DMAX];
-    current_state<T, ROBOT>(E, P.task, cs);
-    if constexpr (TEAM) {
-      T* stage = TeamRows<T, LDS>::bc(col);
-#pragma unroll
-      for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
-    }
-    team_obs = 1;
-  } else write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, env, P.task, out.obs);   // (a reset rewrote the history: leader only)
-  WT_STAMP(8);
-#ifdef SOLO_PHASE_TIMING
-  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[11], (unsigned long long)(clock64() - kstart_));
-#endif
+  write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, env, P.task, out.obs);
   store_env(E, sf, si, L, (idx_t)N, e);
-  WT_STAMP(9);
-#ifdef SOLO_PHASE_TIMING
-  if (TEAM && threadIdx.x == 0) atomicAdd(&solo::solo_phase_cycles[12], (unsigned long long)(clock64() - kstart_));
-#endif
-  }   // mode == MODE_STEP
-  }   // lead
-  if constexpr (TEAM) {
-    // SoloBase.calc_state, solo.py:186-196: [s, s - hist_newest, s - hist_older], element d on lane d mod 16
-    TEAM_SYNC();
-    team_obs = __shfl(team_obs, 0, 16);
-    if (valid && team_obs) {
-      const T* stage = TeamRows<T, LDS>::bc(col);
-      float* o = out.obs + env * (idx_t)(L.D * (1 + L.H));
-#pragma unroll
-      for (int k = 0; k < HK; k++) {
-        const int d = t + 16 * k;
-        if (d < L.D) {
-          const T c = stage[d];
-          o[d] = (float)c;
-          if (L.H >= 1) o[L.D + d] = (float)(c - hk0[k]);
-          if (L.H == 2) o[2 * L.D + d] = (float)(c - hk1[k]);
-        }
-      }
-    }
-#ifdef SOLO_PHASE_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < solo::SOLO_WREC_WAVES) solo::solo_wave_rec[blockIdx.x][8] = (unsigned long long)(clock64() - kstart_);
-#endif
-#ifdef SOLO_WAVE_TIMING
-    __builtin_amdgcn_s_waitcnt(0);     // (vmcnt = lgkmcnt = 0: the stores above have left)
-    if (threadIdx.x == 0 && blockIdx.x < solo::SOLO_WT_WAVES) {
-      wts_[10] = clock64();
-      unsigned long long* w_ = solo::solo_wave_times[blockIdx.x];
-      w_[0] = (unsigned long long)(wts_[3] - wts_[0]); w_[1] = (unsigned long long)(wts_[4] - wts_[3]); w_[2] = (unsigned long long)(wts_[10] - wts_[4]);
-      w_[3] = (unsigned long long)(wall_clock64() - wr0_);
-      for (int i_ = 0; i_ < 10; i_++) w_[6 + i_] = (unsigned long long)(wts_[i_ + 1] > wts_[i_] && wts_[i_] ? wts_[i_ + 1] - wts_[i_] : 0);
-    }
-#endif
-  }
 }
 
-
-
+#ifdef SOLO_WAVE_TIMING
+#define WT_STAMP(i) do { wts_[i] = clock64(); } while (0)
+#else
+#define WT_STAMP(i) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------- team mode (default): the whole step on 16 lanes per env
 // sum over the 16 lanes of a team (every lane ends with the total)
@@ -876,7 +710,7 @@ template <typename T, int ROBOT>
 __global__ void __launch_bounds__(64)
 step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
             Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
-  step_body<T, ROBOT, false>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
+  step_body<T, ROBOT>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
 }
 
 // Two wavefronts per SIMD: the team-mode workgroup (one wavefront, 4 envs) needs 18.4 KB of LDS, so 8 fit a CU, and the
@@ -1221,24 +1055,6 @@ extern "C" {
 
 const char* solorl_last_error(void) { return g_err.c_str(); }
 
-#ifdef SOLO_PHASE_TIMING
-int solorl_debug_phase_cycles(unsigned long long* out16, int reset) {   // (48 values)   // dev builds only (tools/dev/phase_timing.py)
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(solo::solo_phase_cycles), 48 * sizeof(unsigned long long)) != hipSuccess) return -3;
-  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_phase_cycles), z, sizeof(z)) != hipSuccess) return -3; }
-  return 0;
-}
-int solorl_debug_wave_records(unsigned long long* out, int nwaves, int reset) {    // [nwaves][SOLO_WREC_FIELDS]
-  if (nwaves > solo::SOLO_WREC_WAVES) nwaves = solo::SOLO_WREC_WAVES;
-  const size_t bytes = (size_t)nwaves * solo::SOLO_WREC_FIELDS * sizeof(unsigned long long);
-  if (hipDeviceSynchronize() != hipSuccess) return -3;
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(solo::solo_wave_rec), bytes) != hipSuccess) return -3;
-  if (reset) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(solo::solo_wave_rec)) != hipSuccess || hipMemset(p, 0, sizeof(solo::solo_wave_rec)) != hipSuccess) return -3;
-  }
-  return 0;
-}
-#endif
 #ifdef SOLO_WAVE_TIMING
 extern "C" int solorl_debug_wave_times(unsigned long long* out, int nwaves, int reset) {    // [nwaves][SOLO_WT_FIELDS]
   if (nwaves > solo::SOLO_WT_WAVES) nwaves = solo::SOLO_WT_WAVES;
@@ -1248,13 +1064,6 @@ extern "C" int solorl_debug_wave_times(unsigned long long* out, int nwaves, int 
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(solo::solo_wave_times)) != hipSuccess || hipMemset(p, 0, sizeof(solo::solo_wave_times)) != hipSuccess) return -3;
   }
-  return 0;
-}
-#endif
-#ifdef SOLO_PHASE_TIMING
-int solorl_debug_pgs_cycles(unsigned long long* out20, int reset) {
-  if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(solo::solo_pgs_cycles), 20 * sizeof(unsigned long long)) != hipSuccess) return -3;
-  if (reset) { unsigned long long z[20] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(solo::solo_pgs_cycles), z, sizeof(z)) != hipSuccess) return -3; }
   return 0;
 }
 #endif
