@@ -1076,23 +1076,6 @@ SD int team_or16(int x) {
   return x;
 }
 
-// rare path of the collision phase: more than MAX_CONTACTS primitives touch -- keep the deepest (ties: lower id)
-template <typename T, int ROBOT, typename CH>
-SNI int cap_contacts(CH ch, int mask) {
-  const SubCtx<T, ROBOT>& C = ch.get();
-  T dist[NPRIM];
-#pragma unroll
-  for (int p = 0; p < NPRIM; p++) dist[p] = C.dist[p];
-  int keep = 0;
-  for (int p = 0; p < NPRIM; p++) {
-    int rank = 0;
-    for (int q = 0; q < NPRIM; q++)
-      if (q != p) rank += ((mask >> q) & 1) && (dist[q] < dist[p] || (dist[q] == dist[p] && q < p));
-    if (((mask >> p) & 1) && rank < MAX_CONTACTS) keep |= 1 << p;
-  }
-  return keep;
-}
-
 // Collision detection, team mode (replaces phase_detect): the four legs' support points on lanes 0..3, the
 // twelve base points on lanes 4..15, joint-limit tests one joint per lane; masks are OR-reduced over the team.
 // The leader then records the counts and starts the articulated-inertia accumulation with the base link.
@@ -1162,9 +1145,24 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   lbits = team_or16(lbits);
   if (pp.tm_on) sbits = team_or16(sbits);     // (uniform branch)
   if (__popc(mask) > MAX_CONTACTS) {
-    if (lead) C.mask = cap_contacts<T, ROBOT, CH>(ch, mask);
-    TEAM_SYNC();
-    mask = C.mask;                                     // (LDS: written by the leader just above, same wave)
+    // more than MAX_CONTACTS primitives touch (a robot lying on the ground -- the heaviest wavefronts, which set the launch
+    // time): keep the deepest, ties to the lower id.  Lane t ranks primitives t and t+16 against the team's distances in LDS
+    // (the serial version on the leader was a 1 900-instruction non-inlined call that also made this phase save registers on
+    // every call).
+    TEAM_SYNC();                                       // C.dist: written by the primitives' own lanes above
+    int keep = 0;
+    for (int p = t; p < NPRIM; p += 16) {
+      if ((mask >> p) & 1) {
+        const T dp = C.dist[p];
+        int rank = 0;
+        for (int q = 0; q < NPRIM; q++) {
+          const T dq = C.dist[q];
+          rank += (((mask >> q) & 1) && (dq < dp || (dq == dp && q < p))) ? 1 : 0;
+        }
+        if (rank < MAX_CONTACTS) keep |= 1 << p;
+      }
+    }
+    mask = team_or16(keep);
   }
   const int nl = __popc(lbits);
   if (valid && t >= 4 && ((mask >> (t - 4)) & 1)) {    // base contacts: every touching point parks its own three rows

@@ -93,7 +93,7 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
            and "RowLdsIfLi64" not in n]
     assert len(hot) >= 10, sorted(st)[:5]          # 5 phases x 2 robots
     for n in hot:
-        assert st[n]["scratch"] <= 8, (n, st[n])   # (four callee-saved registers around the rare cap_contacts call; at two wavefronts per SIMD there are no AGPRs to park them in)
+        assert st[n]["scratch"] <= 2, (n, st[n])   # (leaf phases: at most one register saved around the body)
         assert st[n]["flat"] <= 11, (n, st[n])     # phase_leg_rt reads PhysParams fields (9 + the treadmill friction, twice) through its reference argument
         assert st[n]["global"] == 0, (n, st[n])
     # the 17 specialised sweeps: whatever their register pressure (the heaviest save callee-saved registers to scratch
