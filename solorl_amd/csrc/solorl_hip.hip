@@ -36,6 +36,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SOLORL_ERR_HIP, std::string(#x ": ") + hipGetErrorString(e_)); } while (0)
 
 constexpr int DMAX = SOLORL_STATE_MAX_OBS;   // 42
+constexpr int HSTRIDE = (DMAX + 3) & ~3;     // fields per history level in the state storage: 44 (whole 64-B sectors, see SX)
 using idx_t = unsigned;   // device-side element indices: 32-bit (solorl_create checks NF*N and O*N < 2^31); 64-bit index
                           // arithmetic made every state access ~10 VALU instructions
 
@@ -46,12 +47,22 @@ struct Layout {
 };
 enum { I_TIMESTEP = 0, I_MASK = 1, I_RNG = 2, I_NEEDRESET = 3, I_ENVID = 4, NI = 5 };   // I_ENVID: slot -> env id
 
+// State storage, "AoSoA-4": slots are grouped in fours (= the four envs of a team-mode wavefront) and a group holds its
+// fields as [field][4], so a group is one contiguous block of NF x 16 B.  The team's lanes (field t, t+16, ... of slot
+// e & 3) then read and write whole 64-B sectors: 4 sectors per wave instruction where the field-major layout of round 1
+// touched 16, and its 16-B partial writes were counted (and paid for) as full 64-B write requests -- 11.0 MB of HBM writes
+// per launch against 3.2 MB of bytes actually stored.  Snapshots use the same indexing over their own slot count.
+SD idx_t SX(int f, idx_t e, int nf) { return (e >> 2) * (idx_t)(nf << 2) + ((idx_t)f << 2) + (e & 3u); }
+
 Layout make_layout(int n, int D, int H) {
   Layout L; int o = 0;
   L.n = n; L.D = D; L.H = H;
+  // every block starts on a multiple of 4 fields = a 64-B sector of the group (SX), and NF is one, so groups are sector-aligned
+  auto align4 = [&]() { o = (o + 3) & ~3; };
   L.pos = o; o += 3; L.quat = o; o += 4; L.v = o; o += 3; L.w = o; o += 3;
-  L.q = o; o += n; L.qd = o; o += n; L.lam = o; o += NPRIM; L.hist = o; o += 2 * DMAX;
+  L.q = o; o += n; L.qd = o; o += n; align4(); L.lam = o; o += NPRIM; align4(); L.hist = o; o += 2 * HSTRIDE; align4();
   L.goal = o; o += 2; L.pot = o++; L.prog = o++; L.goals = o++; L.egoals = o++; L.dr = o; o += 5; L.xyprev = o; o += 2; L.tmy = o++;
+  align4();
   L.NF = o;
   return L;
 }
@@ -110,7 +121,7 @@ template <typename T, int NQ> struct Env {
 
 template <typename T, int NQ>
 SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, idx_t N, idx_t e) {
-  auto F = [&](int f) { return sf[(idx_t)f * N + e]; };
+  auto F = [&](int f) { return sf[SX(f, e, L.NF)]; };
   E.ps.pos = mk(F(L.pos), F(L.pos + 1), F(L.pos + 2));
   E.ps.qx = F(L.quat); E.ps.qy = F(L.quat + 1); E.ps.qz = F(L.quat + 2); E.ps.qw = F(L.quat + 3);
   E.ps.v = mk(F(L.v), F(L.v + 1), F(L.v + 2)); E.ps.w = mk(F(L.w), F(L.w + 1), F(L.w + 2));
@@ -121,11 +132,11 @@ SD void load_env(Env<T, NQ>& E, const T* sf, const int* si, const Layout& L, idx
 #pragma unroll
   for (int k = 0; k < 5; k++) E.dr[k] = F(L.dr + k);
   E.xyprev[0] = F(L.xyprev); E.xyprev[1] = F(L.xyprev + 1); E.tmy = F(L.tmy);
-  E.timestep = si[(idx_t)I_TIMESTEP * N + e]; E.mask = si[(idx_t)I_MASK * N + e]; E.rng = si[(idx_t)I_RNG * N + e];
+  E.timestep = si[SX(I_TIMESTEP, e, NI)]; E.mask = si[SX(I_MASK, e, NI)]; E.rng = si[SX(I_RNG, e, NI)];
 }
 template <typename T, int NQ>
 SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, idx_t N, idx_t e) {
-  auto F = [&](int f, T v) { sf[(idx_t)f * N + e] = v; };
+  auto F = [&](int f, T v) { sf[SX(f, e, L.NF)] = v; };
   F(L.pos, E.ps.pos.x); F(L.pos + 1, E.ps.pos.y); F(L.pos + 2, E.ps.pos.z);
   F(L.quat, E.ps.qx); F(L.quat + 1, E.ps.qy); F(L.quat + 2, E.ps.qz); F(L.quat + 3, E.ps.qw);
   F(L.v, E.ps.v.x); F(L.v + 1, E.ps.v.y); F(L.v + 2, E.ps.v.z);
@@ -137,7 +148,7 @@ SD void store_env(const Env<T, NQ>& E, T* sf, int* si, const Layout& L, idx_t N,
 #pragma unroll
   for (int k = 0; k < 5; k++) F(L.dr + k, E.dr[k]);
   F(L.xyprev, E.xyprev[0]); F(L.xyprev + 1, E.xyprev[1]); F(L.tmy, E.tmy);
-  si[(idx_t)I_TIMESTEP * N + e] = E.timestep; si[(idx_t)I_MASK * N + e] = E.mask; si[(idx_t)I_RNG * N + e] = E.rng;
+  si[SX(I_TIMESTEP, e, NI)] = E.timestep; si[SX(I_MASK, e, NI)] = E.mask; si[SX(I_RNG, e, NI)] = E.rng;
 }
 
 // SoloBase.get_current_state (solo.py:198-222): D values, compile-time indices
@@ -202,13 +213,13 @@ SD void reset_from_snapshot(Env<T, Robot<ROBOT>::NQ>& E, T* sf, const Layout& L,
   E.goal[0] = g0; E.goal[1] = g1; E.goals = T(0); E.egoals = T(0);
 #pragma unroll
   for (int q = 0; q < 5; q++) E.dr[q] = T(0);
-  for (int p = 0; p < NPRIM; p++) sf[(idx_t)(L.lam + p) * N + e] = snf[(idx_t)(L.lam + p) * M + k];
+  for (int p = 0; p < NPRIM; p++) sf[SX(L.lam + p, e, L.NF)] = snf[SX(L.lam + p, k, L.NF)];
   for (int h = 0; h < L.H; h++)
-    for (int d = 0; d < L.D; d++) sf[(idx_t)(L.hist + h * DMAX + d) * N + e] = snf[(idx_t)(L.hist + h * DMAX + d) * M + k];
+    for (int d = 0; d < L.D; d++) sf[SX(L.hist + h * HSTRIDE + d, e, L.NF)] = snf[SX(L.hist + h * HSTRIDE + d, k, L.NF)];
   if (P.task == SOLORL_TASK_POINTGOAL) {
     for (int h = 0; h < L.H; h++) {
-      sf[(idx_t)(L.hist + h * DMAX + L.D - 2) * N + e] = g0 * T(0.5);
-      sf[(idx_t)(L.hist + h * DMAX + L.D - 1) * N + e] = g1 * T(0.5);
+      sf[SX(L.hist + h * HSTRIDE + L.D - 2, e, L.NF)] = g0 * T(0.5);
+      sf[SX(L.hist + h * HSTRIDE + L.D - 1, e, L.NF)] = g1 * T(0.5);
     }
     T dx = E.ps.pos.x - g0, dy = E.ps.pos.y - g1, px = E.xyprev[0] - g0, py = E.xyprev[1] - g1;
     E.pot = sqrt(dx * dx + dy * dy);
@@ -229,7 +240,7 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
 #pragma unroll
   for (int h = 0; h < 2; h++)
 #pragma unroll
-    for (int d = 0; d < DMAX; d++) hv[h][d] = (h < L.H && d < L.D) ? sf[(idx_t)(L.hist + h * DMAX + d) * N + e] : T(0);
+    for (int d = 0; d < DMAX; d++) hv[h][d] = (h < L.H && d < L.D) ? sf[SX(L.hist + h * HSTRIDE + d, e, L.NF)] : T(0);
 #pragma unroll
   for (int d = 0; d < DMAX; d++)
     if (d < L.D) {
@@ -256,7 +267,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   if (e >= (idx_t)N) return;
   LDS lds; lds.lanes = EPB; lds.lane = col;
   Env<T, NQ> E;
-  const idx_t env = (idx_t)si[(idx_t)I_ENVID * N + e];   // state is kept sorted by contact count: slot e holds env `env`
+  const idx_t env = (idx_t)si[SX(I_ENVID, e, NI)];   // state is kept sorted by contact count: slot e holds env `env`
   load_env(E, sf, si, L, (idx_t)N, e);
 
   // ---- A3 apply_action
@@ -279,12 +290,12 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     T cs[DMAX], h0[DMAX];
     current_state<T, ROBOT>(E, P.task, cs);
 #pragma unroll
-    for (int d = 0; d < DMAX; d++) h0[d] = (L.H == 2 && d < L.D) ? sf[(idx_t)(L.hist + d) * N + e] : T(0);   // loads first (see write_obs)
+    for (int d = 0; d < DMAX; d++) h0[d] = (L.H == 2 && d < L.D) ? sf[SX(L.hist + d, e, L.NF)] : T(0);   // loads first (see write_obs)
 #pragma unroll
     for (int d = 0; d < DMAX; d++)
       if (d < L.D) {
-        if (L.H == 2) sf[(idx_t)(L.hist + DMAX + d) * N + e] = h0[d];
-        sf[(idx_t)(L.hist + d) * N + e] = cs[d];
+        if (L.H == 2) sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = h0[d];
+        sf[SX(L.hist + d, e, L.NF)] = cs[d];
       }
   }
   E.xyprev[0] = E.ps.pos.x; E.xyprev[1] = E.ps.pos.y;
@@ -296,7 +307,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
 #pragma unroll
       for (int j = 0; j < NQ; j++) C.tau[j] = tau[j] * sc;
-      E.mask = substep<T, ROBOT>(C, pp, sf + (idx_t)L.lam * N + e, (idx_t)N, lds);
+      E.mask = substep<T, ROBOT>(C, pp, sf + SX(L.lam, e, L.NF), 4u, lds);
     }
     E.ps = C.ps;
   }
@@ -462,11 +473,11 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   // ---- the env's state, HBM -> LDS, all lanes (the state is stored by slot: slot e holds env `env`)
   T a_t = T(0);
   if (valid) {
-    env = (idx_t)si[(idx_t)I_ENVID * NN + e];
-    for (int f = t; f < NPS; f += 16) psv[f] = sf[(idx_t)(L.pos + f) * NN + e];
-    if (t < NER) C.erec[t] = sf[(idx_t)(L.goal + t) * NN + e];
-    if (t < 3) C.irec[t] = si[(idx_t)t * NN + e];
-    for (int p = t; p < NPRIM; p += 16) C.lamp[p] = sf[(idx_t)(L.lam + p) * NN + e];
+    env = (idx_t)si[SX(I_ENVID, e, NI)];
+    for (int f = t; f < NPS; f += 16) psv[f] = sf[SX(L.pos + f, e, L.NF)];
+    if (t < NER) C.erec[t] = sf[SX(L.goal + t, e, L.NF)];
+    if (t < 3) C.irec[t] = si[SX(t, e, NI)];
+    for (int p = t; p < NPRIM; p += 16) C.lamp[p] = sf[SX(L.lam + p, e, L.NF)];
     if (t < NQ && mode == MODE_STEP) a_t = (T)actions[env * NQ + t];
   }
   static_assert(I_TIMESTEP == IR_TIMESTEP && I_MASK == IR_MASK && I_RNG == IR_RNG, "counter order");
@@ -508,9 +519,12 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const int d = t + 16 * k;
       if (d < L.D) {
         const T c = stage[d];
-        if (L.H == 2) { hk1[k] = sf[(idx_t)(L.hist + d) * NN + e]; sf[(idx_t)(L.hist + DMAX + d) * NN + e] = hk1[k]; }
-        sf[(idx_t)(L.hist + d) * NN + e] = c;
+        if (L.H == 2) { hk1[k] = sf[SX(L.hist + d, e, L.NF)]; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = hk1[k]; }
+        sf[SX(L.hist + d, e, L.NF)] = c;
         hk0[k] = c;
+      } else if (d < ((L.D + 3) & ~3)) {               // (pad: the level's last sector is written whole)
+        sf[SX(L.hist + d, e, L.NF)] = T(0);
+        if (L.H == 2) sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = T(0);
       }
     }
   }
@@ -520,11 +534,11 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   for (int ss = 0; ss < P.frame_skip; ss++) {
     const T sc = (ss == 0 || P.hold_torque) ? T(1) : T(0);   // K8: Bullet clears applied torques every step
     if (valid && t < NQ) C.tau[t] = C.tau_base[t] * sc;
-    const int m = substep_team<T, ROBOT>(pp, sf + (idx_t)L.lam * NN + e, NN, lds, t, lead, valid);
+    const int m = substep_team<T, ROBOT>(pp, sf + SX(L.lam, e, L.NF), 4u, lds, t, lead, valid);
     if (lead) C.irec[IR_MASK] = m;
   }
   WT_STAMP(4);
-  if (valid) for (int p = t; p < NPRIM; p += 16) sf[(idx_t)(L.lam + p) * NN + e] = C.lamp[p];
+  if (valid) for (int p = t; p < NPRIM; p += 16) sf[SX(L.lam + p, e, L.NF)] = C.lamp[p];
   WT_STAMP(5);
   // ---- scalar env logic on the leader (values from LDS)
   if (lead) {
@@ -621,19 +635,19 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     // state, every field moved by the team -- HBM for all of them, LDS too for what the rest of this step reads
     const idx_t k = (idx_t)C.irec[IR_SNAP], MM = (idx_t)M;
     for (int f = t; f < L.NF; f += 16) {
-      const T v = snf[(idx_t)f * MM + k];
+      const T v = snf[SX(f, k, L.NF)];
       const bool scalar = f >= L.goal && f < L.goal + NER;
-      if (!scalar) sf[(idx_t)f * NN + e] = v;                     // (the scalars are stored at the end, patched)
+      if (!scalar) sf[SX(f, e, L.NF)] = v;                     // (the scalars are stored at the end, patched)
       if (f < NPS) psv[f] = v;
       else if (scalar && f != L.goal && f != L.goal + 1) C.erec[f - L.goal] = v;     // (the goal just drawn stays)
     }
-    if (t == 1) C.irec[IR_MASK] = sni[(idx_t)I_MASK * MM + k];
+    if (t == 1) C.irec[IR_MASK] = sni[SX(I_MASK, k, NI)];
 #pragma unroll
     for (int kk = 0; kk < HK; kk++) {          // this lane's history elements, for the observation deltas
       const int d = t + 16 * kk;
       if (d < L.D) {
-        if (L.H >= 1) hk0[kk] = snf[(idx_t)(L.hist + d) * MM + k];
-        if (L.H == 2) hk1[kk] = snf[(idx_t)(L.hist + DMAX + d) * MM + k];
+        if (L.H >= 1) hk0[kk] = snf[SX(L.hist + d, k, L.NF)];
+        if (L.H == 2) hk1[kk] = snf[SX(L.hist + HSTRIDE + d, k, L.NF)];
       }
     }
     TEAM_SYNC();
@@ -644,8 +658,8 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
         const int d = t + 16 * kk;
         if (d == L.D - 2 || d == L.D - 1) {
           const T gv = (d == L.D - 2 ? g0 : g1) * T(0.5);
-          if (L.H >= 1) { hk0[kk] = gv; sf[(idx_t)(L.hist + d) * NN + e] = gv; }
-          if (L.H == 2) { hk1[kk] = gv; sf[(idx_t)(L.hist + DMAX + d) * NN + e] = gv; }
+          if (L.H >= 1) { hk0[kk] = gv; sf[SX(L.hist + d, e, L.NF)] = gv; }
+          if (L.H == 2) { hk1[kk] = gv; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = gv; }
         }
       }
     }
@@ -689,9 +703,9 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       }
     }
     // ---- the env's state, LDS -> HBM, all lanes
-    for (int f = t; f < NPS; f += 16) sf[(idx_t)(L.pos + f) * NN + e] = psv[f];
-    if (t < NER) sf[(idx_t)(L.goal + t) * NN + e] = C.erec[t];
-    if (t < 3) si[(idx_t)t * NN + e] = C.irec[t];
+    for (int f = t; f < ((NPS + 3) & ~3); f += 16) sf[SX(L.pos + f, e, L.NF)] = f < NPS ? psv[f] : T(0);     // (whole sectors:
+    sf[SX(L.goal + t, e, L.NF)] = t < NER ? C.erec[t] : T(0);                                                 //  the pads are written too)
+    if (t < 3) si[SX(t, e, NI)] = C.irec[t];
   }
   WT_STAMP(9);
 #ifdef SOLO_WAVE_TIMING
@@ -733,11 +747,11 @@ __global__ void reset_kernel(T* sf, int* si, const T* snf, const int* sni, int M
   if (e >= (idx_t)N) return;
   Env<T, Robot<ROBOT>::NQ> E;
   load_env(E, sf, si, L, (idx_t)N, e);
-  const idx_t env = (idx_t)si[(idx_t)I_ENVID * N + e];
+  const idx_t env = (idx_t)si[SX(I_ENVID, e, NI)];
   reset_from_snapshot<T, ROBOT>(E, sf, L, (idx_t)N, e, env, snf, sni, M, P);
   if (obs) write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, env, P.task, obs);
   store_env(E, sf, si, L, (idx_t)N, e);
-  si[(idx_t)I_NEEDRESET * N + e] = 0;
+  si[SX(I_NEEDRESET, e, NI)] = 0;
 }
 
 template <typename T, int ROBOT>
@@ -746,7 +760,7 @@ __global__ void obs_kernel(const T* sf, const int* si, Layout L, int N, int task
   if (e >= (idx_t)N) return;
   Env<T, Robot<ROBOT>::NQ> E;
   load_env(E, sf, si, L, (idx_t)N, e);
-  write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, (idx_t)si[(idx_t)I_ENVID * N + e], task, obs);
+  write_obs<T, ROBOT>(E, sf, L, (idx_t)N, e, (idx_t)si[SX(I_ENVID, e, NI)], task, obs);
 }
 
 // initial pose of SoloBase.robot_specific_reset (solo.py:291-296) for every env of a buffer
@@ -754,20 +768,20 @@ template <typename T>
 __global__ void init_pose_kernel(T* sf, int* si, Layout L, int N, T tmy) {
   const idx_t e = (idx_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (idx_t)N) return;
-  for (int f = 0; f < L.NF; f++) sf[(idx_t)f * N + e] = T(0);
-  sf[(idx_t)(L.pos + 2) * N + e] = T(0.35);
-  sf[(idx_t)(L.quat + 3) * N + e] = T(1);
-  sf[(idx_t)L.tmy * N + e] = tmy;
-  for (int k = 0; k < NI; k++) si[(idx_t)k * N + e] = 0;
-  si[(idx_t)I_NEEDRESET * N + e] = 1;
-  si[(idx_t)I_ENVID * N + e] = (int)e;
+  for (int f = 0; f < L.NF; f++) sf[SX(f, e, L.NF)] = T(0);
+  sf[SX(L.pos + 2, e, L.NF)] = T(0.35);
+  sf[SX(L.quat + 3, e, L.NF)] = T(1);
+  sf[SX(L.tmy, e, L.NF)] = tmy;
+  for (int k = 0; k < NI; k++) si[SX(k, e, NI)] = 0;
+  si[SX(I_NEEDRESET, e, NI)] = 1;
+  si[SX(I_ENVID, e, NI)] = (int)e;
 }
 
 template <typename T>
 __global__ void copy_env_kernel(const T* sf, const int* si, int N, int src, T* df, int* di, int M, int dst, int NF) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < NF) df[(idx_t)f * M + dst] = sf[(idx_t)f * N + src];
-  if (f < NI) di[(idx_t)f * M + dst] = si[(idx_t)f * N + src];
+  if (f < NF) df[SX(f, (idx_t)dst, NF)] = sf[SX(f, (idx_t)src, NF)];
+  if (f < NI) di[SX(f, (idx_t)dst, NI)] = si[SX(f, (idx_t)src, NI)];
 }
 
 // ---- contact-count sorting (divergence control for the PGS sweep)
@@ -782,7 +796,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
   const int t = threadIdx.x, nt = blockDim.x;
   const int chunk = (N + nt - 1) / nt, lo = t * chunk, hi = lo + chunk < N ? lo + chunk : N;
   int c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = lo; i < hi; i++) { int k = __popc(si[(idx_t)I_MASK * N + i] & 0xFFFFF); k = k > 8 ? 8 : k; c[k]++; }
+  for (int i = lo; i < hi; i++) { int k = __popc(si[SX(I_MASK, (idx_t)i, NI)] & 0xFFFFF); k = k > 8 ? 8 : k; c[k]++; }
 #pragma unroll
   for (int k = 0; k < 9; k++) cnt[t][k] = c[k];
   __syncthreads();
@@ -798,7 +812,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
 #pragma unroll
   for (int k = 0; k < 9; k++) off[k] = base[k] + cnt[t][k];
   for (int i = lo; i < hi; i++) {
-    int k = __popc(si[(idx_t)I_MASK * N + i] & 0xFFFFF); k = k > 8 ? 8 : k;
+    int k = __popc(si[SX(I_MASK, (idx_t)i, NI)] & 0xFFFFF); k = k > 8 ? 8 : k;
     int d = 0;
 #pragma unroll
     for (int q = 0; q < 9; q++) if (q == k) d = off[q]++;
@@ -813,8 +827,8 @@ __global__ void gather_state_kernel(const T* __restrict__ sf, const int* __restr
   if (j >= N) return;
   const int src = perm[j];
   const int f = blockIdx.y;
-  if (f < NF) df[(idx_t)f * N + j] = sf[(idx_t)f * N + src];
-  else di[(idx_t)(f - NF) * N + j] = si[(idx_t)(f - NF) * N + src];
+  if (f < NF) df[SX(f, (idx_t)j, NF)] = sf[SX(f, (idx_t)src, NF)];
+  else di[SX(f - NF, (idx_t)j, NI)] = si[SX(f - NF, (idx_t)src, NI)];
 }
 
 // ---- fused GAE / discounted returns (agents/ppo/storage.py:35-55): one thread per env walks the rollout
@@ -1012,7 +1026,7 @@ template <typename T> int build_snapshots_t(solorl_env* h) {
   // zero-torque control steps is copied into snapshot slot k - settle_min.
   // With the treadmill the settle depends on which side the strip lies: a second set of snapshots (slots nsettle..) for -offset.
   T* tf = nullptr; int* ti = nullptr;
-  HIP_TRY(hipMalloc(&tf, sizeof(T) * h->L.NF)); HIP_TRY(hipMalloc(&ti, sizeof(int) * NI));
+  HIP_TRY(hipMalloc(&tf, sizeof(T) * h->L.NF * 4)); HIP_TRY(hipMalloc(&ti, sizeof(int) * NI * 4));   // (one slot group)
   Outputs none; memset(&none, 0, sizeof none);
   const int nsettle = h->cfg.settle_max - h->cfg.settle_min + 1;
   for (int side = 0; side < (h->cfg.use_treadmill ? 2 : 1); side++) {
@@ -1146,13 +1160,14 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     h->epw = epw;
   }
   auto cleanup = [&](int code) { solorl_destroy(h); return code; };
-  if ((unsigned long long)h->L.NF * (unsigned long long)num_envs >= (1ull << 31) ||
+  const size_t Np = ((size_t)num_envs + 3) & ~(size_t)3, Mp = ((size_t)h->M + 3) & ~(size_t)3;      // slot groups of 4 (SX)
+  if ((unsigned long long)h->L.NF * (unsigned long long)Np >= (1ull << 31) ||
       (unsigned long long)(h->L.D * (1 + h->L.H)) * (unsigned long long)num_envs >= (1ull << 31))
     return cleanup(fail(SOLORL_ERR_INVALID, "num_envs too large for 32-bit element indices"));
-  if (hipMalloc(&h->sf, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state"));
-  if (hipMalloc(&h->si, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
-  if (hipMalloc(&h->snf, h->tsize * h->L.NF * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
-  if (hipMalloc(&h->sni, sizeof(int) * NI * (size_t)h->M) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
+  if (hipMalloc(&h->sf, h->tsize * h->L.NF * Np) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state"));
+  if (hipMalloc(&h->si, sizeof(int) * NI * Np) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate"));
+  if (hipMalloc(&h->snf, h->tsize * h->L.NF * Mp) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc snapshot"));
+  if (hipMalloc(&h->sni, sizeof(int) * NI * Mp) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc isnapshot"));
   {
     double dyn0[NDYN] = {h->goal_radius, 0.0, 0.0, 0.0};
     if (hipMalloc(&h->dyn, sizeof dyn0) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc dyn"));
@@ -1162,8 +1177,8 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
                      // padding they save at every batch size (65 536 envs: 29.5 M vs 23.8 M env-steps/s); SOLORL_SORT=1 enables it
   if (const char* ev = getenv("SOLORL_SORT")) h->sort = atoi(ev) != 0 && num_envs >= 2;
   if (h->sort) {
-    if (hipMalloc(&h->sf2, h->tsize * h->L.NF * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state2"));
-    if (hipMalloc(&h->si2, sizeof(int) * NI * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate2"));
+    if (hipMalloc(&h->sf2, h->tsize * h->L.NF * Np) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc state2"));
+    if (hipMalloc(&h->si2, sizeof(int) * NI * Np) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc istate2"));
     if (hipMalloc(&h->perm, sizeof(int) * (size_t)num_envs) != hipSuccess) return cleanup(fail(SOLORL_ERR_HIP, "hipMalloc perm"));
   }
   dim3 g((num_envs + 255) / 256), b(256);
@@ -1276,9 +1291,10 @@ int solorl_increment_curriculum(solorl_env* h, double value) {
 static int find_slot(solorl_env* h, int env, int* slot) {
   // the state is kept sorted by contact count: look the env up in the slot -> env-id map
   if (!h->sort) { *slot = env; return 0; }
-  std::vector<int> ids(h->N);
-  HIP_TRY(hipMemcpy(ids.data(), h->si + (size_t)I_ENVID * h->N, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost));
-  for (int s = 0; s < h->N; s++) if (ids[s] == env) { *slot = s; return 0; }
+  const size_t Np = ((size_t)h->N + 3) & ~(size_t)3;
+  std::vector<int> all(NI * Np);
+  HIP_TRY(hipMemcpy(all.data(), h->si, sizeof(int) * NI * Np, hipMemcpyDeviceToHost));
+  for (int s = 0; s < h->N; s++) if (all[(size_t)(s >> 2) * (NI << 2) + ((size_t)I_ENVID << 2) + (s & 3)] == env) { *slot = s; return 0; }
   return fail(SOLORL_ERR_INVALID, "env id not found in slot map");
 }
 
@@ -1287,23 +1303,25 @@ int solorl_get_state(solorl_env* h, int i, solorl_env_state* out) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   { int rc_ = find_slot(h, i, &i); if (rc_) return rc_; }
+  // slot i of the AoSoA-4 storage (SX): its fields are 4 elements apart, starting at element (i >> 2) * NF * 4 + (i & 3)
+  const size_t slot0f = (size_t)(i >> 2) * ((size_t)h->L.NF << 2) + (size_t)(i & 3), slot0i = (size_t)(i >> 2) * ((size_t)NI << 2) + (size_t)(i & 3);
   std::vector<double> f(h->L.NF);
   int iv[NI];
   if (h->f64) {
-    HIP_TRY(hipMemcpy2D(f.data(), sizeof(double), (const char*)h->sf + sizeof(double) * (size_t)i, sizeof(double) * (size_t)h->N, sizeof(double), h->L.NF, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(f.data(), sizeof(double), (const char*)h->sf + sizeof(double) * slot0f, sizeof(double) * 4, sizeof(double), h->L.NF, hipMemcpyDeviceToHost));
   } else {
     std::vector<float> ff(h->L.NF);
-    HIP_TRY(hipMemcpy2D(ff.data(), sizeof(float), (const char*)h->sf + sizeof(float) * (size_t)i, sizeof(float) * (size_t)h->N, sizeof(float), h->L.NF, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(ff.data(), sizeof(float), (const char*)h->sf + sizeof(float) * slot0f, sizeof(float) * 4, sizeof(float), h->L.NF, hipMemcpyDeviceToHost));
     for (int k = 0; k < h->L.NF; k++) f[k] = ff[k];
   }
-  HIP_TRY(hipMemcpy2D(iv, sizeof(int), (const char*)h->si + sizeof(int) * (size_t)i, sizeof(int) * (size_t)h->N, sizeof(int), NI, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(iv, sizeof(int), (const char*)h->si + sizeof(int) * slot0i, sizeof(int) * 4, sizeof(int), NI, hipMemcpyDeviceToHost));
   const Layout& L = h->L;
   memset(out, 0, sizeof *out);
   for (int k = 0; k < 3; k++) { out->pos[k] = f[L.pos + k]; out->lin_vel[k] = f[L.v + k]; out->ang_vel[k] = f[L.w + k]; }
   for (int k = 0; k < 4; k++) out->quat[k] = f[L.quat + k];
   for (int j = 0; j < h->n; j++) { out->q[j] = f[L.q + j]; out->qd[j] = f[L.qd + j]; }
   for (int p = 0; p < NPRIM; p++) out->lambda_prev[p] = f[L.lam + p];
-  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) out->hist[hh][d] = f[L.hist + hh * DMAX + d];
+  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) out->hist[hh][d] = f[L.hist + hh * HSTRIDE + d];
   out->goal[0] = f[L.goal]; out->goal[1] = f[L.goal + 1]; out->potential = f[L.pot]; out->progress = f[L.prog];
   out->goals_reached = f[L.goals]; out->env_goals_reached = f[L.egoals];
   for (int k = 0; k < 5; k++) out->dr[k] = f[L.dr + k];
@@ -1319,12 +1337,13 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
   const int env_id = i;
   { int rc_ = find_slot(h, i, &i); if (rc_) return rc_; }
   const Layout& L = h->L;
+  const size_t slot0f = (size_t)(i >> 2) * ((size_t)L.NF << 2) + (size_t)(i & 3), slot0i = (size_t)(i >> 2) * ((size_t)NI << 2) + (size_t)(i & 3);
   std::vector<double> f(L.NF, 0.0);
   for (int k = 0; k < 3; k++) { f[L.pos + k] = in->pos[k]; f[L.v + k] = in->lin_vel[k]; f[L.w + k] = in->ang_vel[k]; }
   for (int k = 0; k < 4; k++) f[L.quat + k] = in->quat[k];
   for (int j = 0; j < h->n; j++) { f[L.q + j] = in->q[j]; f[L.qd + j] = in->qd[j]; }
   for (int p = 0; p < NPRIM; p++) f[L.lam + p] = in->lambda_prev[p];
-  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) f[L.hist + hh * DMAX + d] = in->hist[hh][d];
+  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) f[L.hist + hh * HSTRIDE + d] = in->hist[hh][d];
   f[L.goal] = in->goal[0]; f[L.goal + 1] = in->goal[1]; f[L.pot] = in->potential; f[L.prog] = in->progress;
   f[L.goals] = in->goals_reached; f[L.egoals] = in->env_goals_reached;
   for (int k = 0; k < 5; k++) f[L.dr + k] = in->dr[k];
@@ -1332,13 +1351,13 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
   int iv[NI]; iv[I_TIMESTEP] = in->timestep; iv[I_MASK] = in->contact_mask; iv[I_RNG] = in->rng_counter; iv[I_NEEDRESET] = in->need_reset;
   iv[I_ENVID] = env_id;
   if (h->f64) {
-    HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(double) * (size_t)i, sizeof(double) * (size_t)h->N, f.data(), sizeof(double), sizeof(double), L.NF, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(double) * slot0f, sizeof(double) * 4, f.data(), sizeof(double), sizeof(double), L.NF, hipMemcpyHostToDevice));
   } else {
     std::vector<float> ff(L.NF);
     for (int k = 0; k < L.NF; k++) ff[k] = (float)f[k];
-    HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(float) * (size_t)i, sizeof(float) * (size_t)h->N, ff.data(), sizeof(float), sizeof(float), L.NF, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D((char*)h->sf + sizeof(float) * slot0f, sizeof(float) * 4, ff.data(), sizeof(float), sizeof(float), L.NF, hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMemcpy2D((char*)h->si + sizeof(int) * (size_t)i, sizeof(int) * (size_t)h->N, iv, sizeof(int), sizeof(int), NI, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D((char*)h->si + sizeof(int) * slot0i, sizeof(int) * 4, iv, sizeof(int), sizeof(int), NI, hipMemcpyHostToDevice));
   if (!in->need_reset) h->reset_called = true;
   return 0;
 }
