@@ -62,6 +62,7 @@ template <typename T> struct PhysParams {
   T dt, gravity, erp, slop, warm, damping, vmax, qlim, inv_dt;
   int iterations;
   int tm_on; T tm_hw, tm_mu;   // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
+  int pgs_pipe;                // team-mode sweep: software-pipelined (a wavefront per SIMD) or plain (two per SIMD), see pgs_team_variant
   int urdf_inertia;            // K2: 0 = Bullet's default box inertia from the collision AABB, 1 = the URDF tensor (use_urdf_inertia)
   T resid_thr;                 // sqrt(solver_residual_threshold): velocity-level change below which a solve stops (K7); < 0: never
 };
@@ -1354,7 +1355,11 @@ template <typename T> SD T team_red8(T x) {      // sum over the 8 lanes of a ha
 }
 
 // EXIT: with the K7 residual test (solver_residual_threshold > 0); the default fixed-iteration solve carries none of it.
-template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT>
+// PIPE: the next slot's J'.acc reduction is started one slot early and corrected with two couplings (3 more instructions per
+//   slot, a 6-operation shorter dependency chain).  Measured: faster when a wavefront has its SIMD to itself (<= 4096 envs:
+//   0.172 vs 0.180 ms per step), slower when two wavefronts share one and issue slots are what counts (8192 envs: 0.229 vs
+//   0.223 ms) -- the launcher picks by grid size (PhysParams::pgs_pipe).  The K7 variants are always pipelined.
+template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT, bool PIPE = true>
 SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // (the residual threshold of K7 reaches the sweep through the rows: phase_finish_team stores it per row, in the row's units)
   using TRW = TeamRows<T, LDS>;
@@ -1426,8 +1431,10 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // couplings with the predecessor slot (wrapping around: the first slot follows the last one of the previous sweep)
   static_for<n>([&](auto ic) {
     constexpr int i = decltype(ic)::value, p = (i + n - 1) % n;
-    eo[i] = team_red8(J0[i] * B01[p].x + J1[i] * B01[p].y + J2[i] * B2[p]);
-    ex[i] = team_red8(J0[i] * X01[p].x + J1[i] * X01[p].y + J2[i] * X2[p]);
+    if constexpr (PIPE) {
+      eo[i] = team_red8(J0[i] * B01[p].x + J1[i] * B01[p].y + J2[i] * B2[p]);
+      ex[i] = team_red8(J0[i] * X01[p].x + J1[i] * X01[p].y + J2[i] * X2[p]);
+    } else { eo[i] = T(0); ex[i] = T(0); (void)p; }
   });
   auto jdot = [&](int, T j0, T j1, T j2, T r8) -> T { return team_red8(fm(j0, a01.x, fm(j1, a01.y, fm(j2, a2, r8)))); };   // J'.acc - rhs'
   T dpre = jdot(0, J0[0], J1[0], J2[0], rh[0]);
@@ -1458,13 +1465,11 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       constexpr int i = decltype(ic)::value, in = (i + 1) % n;
       constexpr bool fric = i >= LIM + NNS;
       // next slot's reduction on the accumulators as they are now (without this slot's update)
-#ifdef SOLO_PGS_NOPIPE    // plain in-order reduction: 3 instructions fewer per slot, a 6-operation longer dependency chain
-      const T dnext = T(0);
-      const T d = jdot(i, J0[i], J1[i], J2[i], rh[i]);
-#else
-      const T dnext = jdot(in, J0[in], J1[in], J2[in], rh[in]);
-      const T d = fm(ex[i], delxp, fm(eo[i], delp, dpre));
-#endif
+      T dnext = T(0), d;
+      if constexpr (PIPE) {
+        dnext = jdot(in, J0[in], J1[in], J2[in], rh[in]);
+        d = fm(ex[i], delxp, fm(eo[i], delp, dpre));
+      } else d = jdot(i, J0[i], J1[i], J2[i], rh[i]);     // plain in-order reduction
       T hi = T(0);
       if constexpr (fric) {   // impulse of this contact's normal row: normal slot c/2, half c&1
         constexpr int c = i - LIM - NNS;
@@ -1510,7 +1515,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
 }
 
 template <typename T, int ROBOT, typename LDS>
-SD void phase_pgs_team(int iterations, bool early_exit, const LDS lds, int t) {
+SD void phase_pgs_team(int iterations, bool early_exit, bool pipe, const LDS lds, int t) {
   constexpr int LN = LDS::LANES;
   int nlt, nc, ncmax, anylim;
   team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
@@ -1520,10 +1525,21 @@ SD void phase_pgs_team(int iterations, bool early_exit, const LDS lds, int t) {
     if ((unsigned long long)ncmax > solo_wave_times[blockIdx.x][5]) solo_wave_times[blockIdx.x][5] = (unsigned long long)ncmax;
   }
 #endif
+  // Wave priority by the length of this sweep: with two wavefronts per SIMD (more than 4096 envs) the launch still ends with
+  // its slowest wavefront, and VALU issue between co-resident waves is arbitrated by priority first -- the heavy wave should run
+  // as if alone and the light one fill its gaps, not the reverse.
+#ifndef SOLO_NO_SETPRIO
+  if (ncmax >= 7) __builtin_amdgcn_s_setprio(3);
+  else if (ncmax >= 5) __builtin_amdgcn_s_setprio(2);
+  else if (ncmax >= 3) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
 #define SOLO_SWEEP_L(N_, F_) do { if (early_exit) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, true>(iterations, lds, t); \
                                                     else pgs_team_variant<T, LDS, 0, N_, F_, true>(iterations, lds, t); } \
-                                  else { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false>(iterations, lds, t); \
-                                         else pgs_team_variant<T, LDS, 0, N_, F_, false>(iterations, lds, t); } } while (0)
+                                  else if (pipe) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false>(iterations, lds, t); \
+                                                   else pgs_team_variant<T, LDS, 0, N_, F_, false>(iterations, lds, t); } \
+                                  else { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false, false>(iterations, lds, t); \
+                                         else pgs_team_variant<T, LDS, 0, N_, F_, false, false>(iterations, lds, t); } } while (0)
   switch (ncmax) {       // wave-uniform
     case 0:
       if (anylim) { if (early_exit) pgs_team_variant<T, LDS, 1, 0, 0, true>(iterations, lds, t); else pgs_team_variant<T, LDS, 1, 0, 0, false>(iterations, lds, t); }
@@ -1638,7 +1654,7 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
 #ifdef SOLO_DUP_FINISH
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #endif
-  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.resid_thr >= T(0), lds, t);
+  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.resid_thr >= T(0), pp.pgs_pipe != 0, lds, t);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
   return lead ? (ch.get().mask | strip_feet_bits(ch.get().smask)) : 0;
 }

@@ -953,6 +953,8 @@ struct solorl_env {
   bool spread = true;
   bool team = false;   // 16 lanes per env (set at create: default true)
   int lds_poison_on = 0; unsigned lds_poison = 0;   // SOLORL_POISON_LDS test hook
+  int simds = 1024;          // SIMDs of the device (4 per CU): grids up to this size have a SIMD per wavefront
+  int pipe_override = -1;    // SOLORL_PGS_PIPE=0/1 (dev A/B)
 };
 
 namespace {
@@ -976,6 +978,7 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   p.iterations = c.solver_iterations;
   p.tm_on = c.use_treadmill; p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
   p.urdf_inertia = c.use_urdf_inertia ? 1 : 0;
+  p.pgs_pipe = 1;
   p.resid_thr = c.solver_residual_threshold > 0 ? (T)sqrt(c.solver_residual_threshold) : T(-1);
   return p;
 }
@@ -988,8 +991,14 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
     using TeamLds = RowLds<T, 4>;
     const size_t team_smem = TeamCtx<T, ROBOT, TeamLds>::bytes;
     static_assert(sizeof(T) == 8 || TeamCtx<T, ROBOT, TeamLds>::bytes <= 20480, "team-mode LDS must allow 8 workgroups per CU (two wavefronts per SIMD)");
+    PhysParams<T> pp = make_phys<T>(h->cfg);
+    // Pipelined sweep while every wavefront has a SIMD to itself, plain sweep above that (pgs_team_variant: 8192 envs 0.226 ->
+    // 0.210 ms per step).  The two are re-associations of the same sums, so an env's last bits depend on which side of
+    // h->simds workgroups its batch is; SOLORL_PGS_PIPE=1 (or 0) pins one variant for every batch size.
+    pp.pgs_pipe = (int)grid.x <= h->simds ? 1 : 0;
+    if (h->pipe_override >= 0) pp.pgs_pipe = h->pipe_override;
     hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
-                       make_env_params(h), make_phys<T>(h->cfg), actions, out, mode);
+                       make_env_params(h), pp, actions, out, mode);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1156,6 +1165,8 @@ int solorl_create(const solorl_config* cfg, int num_envs, int device_id, uint64_
     if (const char* ev = getenv("SOLORL_SPREAD")) h->spread = atoi(ev) != 0;
     h->team = true;   // measured (tools/dev/bench_n.py): team mode wins at every batch size, 1k .. 262k envs; lane mode: SOLORL_TEAM=0
     if (const char* ev = getenv("SOLORL_TEAM")) h->team = atoi(ev) != 0;
+    if (const char* ev = getenv("SOLORL_PGS_PIPE")) h->pipe_override = atoi(ev) != 0;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->simds = 4 * prop.multiProcessorCount; }
     if (const char* ev = getenv("SOLORL_POISON_LDS")) { h->lds_poison_on = 1; h->lds_poison = (unsigned)strtoul(ev, nullptr, 0); }
     h->epw = epw;
   }

@@ -101,10 +101,10 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
     # is register-only -- no scratch, no LDS read, no global or FLAT access (its only LDS writes are the cold block that
     # publishes a team's result when its residual falls below the K7 threshold) -- at 26 VALU instructions per slot
     sweeps = devcode.loop_stats(build.LIB, "pgs_team_variantIfNS")
-    assert len(sweeps) == 34               # 17 slot sets x {fixed iteration count (default), K7 residual exit}
+    assert len(sweeps) == 50               # 17 slot sets x {pipelined (default), K7 residual exit} + 16 plain ones (SOLORL_PGS_PIPE=0)
     for n, s in sweeps.items():
-        m = re.search(r"Li(\d)ELi(\d)ELi(\d)ELb(\d)EEE", n)
-        lim, nn, nf, early = (int(x) for x in m.groups())
+        m = re.search(r"Li(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)EEE", n)
+        lim, nn, nf, early, pipe = (int(x) for x in m.groups())
         nslots = lim + nn + nf
         if nn + nf == 0:
             continue                       # (the limit-only sweep is 1 slot)

@@ -98,12 +98,15 @@ def test_config5_full_size_8192_envs(gpu_device):
         assert st["episodes"] == int(n_done.sum()) and st["episode_length"] <= 50.0
         outs.append((o.clone(), r.clone(), n_done.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    # (a 6144-env shard: above 4096 envs the engine uses the plain sweep, below it the pipelined one -- same sums, other
+    # association -- so bitwise equality holds between batches on the same side; SOLORL_PGS_PIPE pins one variant)
+    off = N // 4
     env_a = SoloVecEnv(c, N, device="cuda:0", seed=4)
-    env_b = SoloVecEnv(c, N // 2, device="cuda:0", seed=4, env_id_offset=N // 2)
+    env_b = SoloVecEnv(c, N - off, device="cuda:0", seed=4, env_id_offset=off)
     env_a.reset(); env_b.reset()
     for t in range(60):
-        oa, _, _, _ = env_a.step_inplace(acts[t % 32]); ob, _, _, _ = env_b.step_inplace(acts[t % 32][N // 2:].contiguous())
-    assert torch.equal(oa[N // 2:], ob)
+        oa, _, _, _ = env_a.step_inplace(acts[t % 32]); ob, _, _, _ = env_b.step_inplace(acts[t % 32][off:].contiguous())
+    assert torch.equal(oa[off:], ob)
 
 
 # ------------------------------------------------------------------------------------------------ pointgoal branches
@@ -363,6 +366,43 @@ def test_episode_stat_accumulators(gpu_device):
 
 
 # ------------------------------------------------------------------------------------------------ K7 early exit (opt-in)
+def test_plain_sweep_variant_vs_oracle(gpu_device):
+    """Above one wavefront per SIMD (more than 4096 envs on an MI355X) the team-mode sweep runs without the software
+    pipelining (3 instructions fewer per slot).  Forced here at a size the oracle can follow (SOLORL_PGS_PIPE=0): same
+    per-step bounds as the default variant, and the two variants agree with each other to rounding."""
+    from solorl_amd.vec_env import SoloVecEnv
+    from oracle.oracle_py import Oracle
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    N = 128
+    envs = {}
+    for pipe in (0, 1):
+        os.environ["SOLORL_PGS_PIPE"] = str(pipe)
+        try:
+            envs[pipe] = SoloVecEnv(c, N, device="cuda:0", seed=3)
+        finally:
+            del os.environ["SOLORL_PGS_PIPE"]
+        envs[pipe].reset()
+    orc = Oracle(c, N, seed=3, threads=8); orc.reset()
+    rng = np.random.default_rng(0)
+    dq, dv = [], []
+    for t in range(30):
+        for i in range(N):
+            s = envs[0].get_state(i)
+            orc.set_state(i, s); envs[1].set_state(i, s)
+        a = rng.uniform(-1.2, 1.2, size=(N, 12)).astype(np.float32) * (0.3 if t < 15 else 1.0)
+        ta = torch.from_numpy(a).cuda()
+        _, _, d0, _ = envs[0].step(ta); _, _, d1, _ = envs[1].step(ta); _, _, od, _ = orc.step(a.astype(np.float64))
+        d0 = d0.cpu().numpy(); d1 = d1.cpu().numpy()
+        for i in range(N):
+            if d0[i] or d1[i] or od[i]:
+                continue
+            q0 = np.array(envs[0].get_state(i).q)
+            dq.append(np.abs(q0 - np.array(orc.get_state(i).q)).max())
+            dv.append(np.abs(q0 - np.array(envs[1].get_state(i).q)).max())
+    assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 1e-3, (np.median(dq), np.percentile(dq, 90))
+    assert np.median(dv) < 1e-5, np.median(dv)
+
+
 @pytest.mark.parametrize("team", [1, 0])
 def test_residual_threshold_early_exit_vs_oracle(gpu_device, team):
     """solver_residual_threshold = 1e-7 (PyBullet's solverResidualThreshold, SURVEY Appendix B K7; opt-in): every env's

@@ -1,5 +1,5 @@
 """Steady-state step time vs batch size (not a pytest file): burn-in of 450 steps, then the median of 3 graph replays of
-K steps.  usage: bench_sizes.py [N ...]      env: BENCH_CFG=walk|pd50 (config 5: PD path, episode length 50)"""
+K steps.  usage: bench_sizes.py [N ...]      env: BENCH_CFG=walk|pd50 (config 5: PD path, episode length 50), BENCH_THR=1e-7 (K7 residual threshold)"""
 import os, sys, time, statistics
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,7 @@ for N in sizes:
     amp = 1.0
     if which == "pd50":
         c.control = CONTROL_PD; c.episode_length = 50; amp = 0.3
+    c.solver_residual_threshold = float(os.environ.get("BENCH_THR", "0"))      # K7 early exit (opt-in)
     env = SoloVecEnv(c, N, device="cuda:0", seed=1); env.reset()
     g = torch.Generator(device="cuda:0"); g.manual_seed(1234)
     a = (torch.rand(64, N, 12, device="cuda:0", generator=g) * 2 - 1) * amp
