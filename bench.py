@@ -235,8 +235,8 @@ def main(argv=None):
     try:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for t in range(K):
+        with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if world > 1 else {})):   # (the process group's watchdog thread
+            for t in range(K):                                                                             #  must not invalidate the capture)
                 env.step_inplace(acts[t % R])
     except Exception:
         graph, launch = None, "eager"
@@ -283,10 +283,8 @@ def main(argv=None):
         # BASELINE config 3 / 4: the full PPO loop (rollout + GAE + clipped update) on the same engine; never fatal
         try:
             ppo = ppo_leg(env, dev, world, args.ppo_steps, args.ppo_epoch)
-        except Exception as ex:
-            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}
-            if world > 1:           # a failure on one rank must not leave the others in a collective
-                raise
+        except Exception as ex:     # (ranks run identical code on identical devices: a failure here is symmetric, nobody is
+            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}     #  left waiting in a collective; the headline line is still printed)
 
     if rank == 0:
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim

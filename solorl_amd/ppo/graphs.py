@@ -23,6 +23,12 @@ from .fused import fused_ppo_loss
 from .ppo import PPO
 
 
+def capture_kwargs():
+    """With a process group up, its watchdog thread issues HIP calls of its own; a capture in the default "global" error mode
+    would be invalidated by them.  Thread-local mode confines the capture's checks to the capturing thread."""
+    return {"capture_error_mode": "thread_local"} if D.world() > 1 else {}
+
+
 def _side_stream_warmup(fn, iters=3):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -65,7 +71,7 @@ class GraphedRollout:
             # is allocated inside the capture (private pool); cuBLAS/hipBLASLt workspaces were created by the
             # eager policy calls that precede the first rollout (train(): reset + get_value warm-up).
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **capture_kwargs()):
                 self._body()
             self.graph = g
         self.graph.replay()
@@ -150,13 +156,13 @@ class GraphedPPO(PPO):
         self._split = D.world() > 1
         pool = torch.cuda.graph_pool_handle()
         self._g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1, pool=pool):
+        with torch.cuda.graph(self._g1, pool=pool, **capture_kwargs()):
             fwd_bwd()
             if not self._split:
                 opt_step()
         if self._split:                       # the RCCL all-reduce of the flat bucket runs between two graphs
             self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2, pool=pool):
+            with torch.cuda.graph(self._g2, pool=pool, **capture_kwargs()):
                 opt_step()
         with torch.no_grad():                 # capture does not execute, but be explicit about the state we start from
             self._stats.zero_(); self._off.zero_()
