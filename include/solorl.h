@@ -126,7 +126,7 @@ typedef struct solorl_info_soa {
 /* Physical + bookkeeping state of ONE env in a fixed, precision-independent (double) layout;
  * used by solorl_get_state/solorl_set_state (HOST pointers) for parity tests. */
 #define SOLORL_STATE_MAX_DOF 12
-#define SOLORL_STATE_MAX_PRIMS 20
+#define SOLORL_STATE_MAX_PRIMS 24
 #define SOLORL_STATE_MAX_OBS 42
 typedef struct solorl_env_state {
   double pos[3], quat[4] /* x y z w */, lin_vel[3], ang_vel[3];
@@ -137,7 +137,7 @@ typedef struct solorl_env_state {
   double dr[5];                                /* stand, joint_pose, torque, balance, progress */
   double treadmill_y;                          /* centre line of the treadmill strip (+-treadmill_offset; 0 if unused) */
   int32_t timestep, need_reset;
-  int32_t contact_mask;  /* bit p (0..19): primitive p was in contact in the last sub-step; bit 20+f: foot f's contact
+  int32_t contact_mask;  /* bit p (0..23): primitive p was in contact in the last sub-step; bit 24+f: foot f's contact
                           * was on the treadmill strip (hidden from the feet sensor) */
   int32_t rng_counter;
 } solorl_env_state;

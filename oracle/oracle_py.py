@@ -58,7 +58,7 @@ class Oracle:
         self.L.oracle_dims(self.h, C.byref(o), C.byref(a), C.byref(n))
         self.O, self.A, self.N = o.value, a.value, n.value
         self.nv = 6 + self.A
-        self.np = 20
+        self.np = 24          # SOLORL_MAX_PRIMS (buffers for the low-level hooks)
         self.L.oracle_set_threads(self.h, threads)
 
     def __del__(self):

@@ -17,7 +17,7 @@ PRECISION_F32, PRECISION_F64 = 0, 1
 TASKS = {"stand": TASK_STAND, "walk": TASK_WALK, "pointgoal": TASK_POINTGOAL}
 CONTROLS = {"torque": CONTROL_TORQUE, "pd": CONTROL_PD, "fpd": CONTROL_PD, "fixed_pd": CONTROL_PD}
 
-MAX_DOF, MAX_PRIMS, MAX_OBS = 12, 20, 42
+MAX_DOF, MAX_PRIMS, MAX_OBS = 12, 24, 42
 
 
 class SoloConfig(C.Structure):

@@ -30,7 +30,7 @@ constexpr int MAX_CONTACTS = 8;
 constexpr int MAX_LIMITS = 2;
 constexpr int MAX_ROWS = MAX_LIMITS + 3 * MAX_CONTACTS;   // 26
 constexpr int ROW_CORE = 20;                              // Jh6 JL3 W6 Y3 rhs dinv
-constexpr int NPRIM = 20;
+constexpr int NPRIM = 24;                                // 12 base points, knee + foot per leg (12 + 2 leg + i), Solo12: shoulder housing per leg (20 + leg)
 constexpr double LIMIT_WINDOW = 0.5;
 constexpr double DISC_EPS2 = 1e-12;
 
@@ -50,10 +50,12 @@ template <int N, typename F> SD void static_for(F&& f) { static_for_impl<N>(f, s
 template <int ROBOT> struct Robot;
 template <> struct Robot<0> {
   static constexpr int NJ = 2, NQ = 8, NL = 13;
+  static constexpr bool SHOULDER = false;                  // no HAA joint, no shoulder housing
   static constexpr const solorl_model_data& MD = SOLORL_MODEL_SOLO8;
 };
 template <> struct Robot<1> {
   static constexpr int NJ = 3, NQ = 12, NL = 17;
+  static constexpr bool SHOULDER = true;                   // primitives 20..23: the shoulder housings (disc about the link's x axis)
   static constexpr const solorl_model_data& MD = SOLORL_MODEL_SOLO12;
 };
 
@@ -66,9 +68,9 @@ template <typename T> struct PhysParams {
   int urdf_inertia;            // K2: 0 = Bullet's default box inertia from the collision AABB, 1 = the URDF tensor (use_urdf_inertia)
   T resid_thr;                 // sqrt(solver_residual_threshold): velocity-level change below which a solve stops (K7); < 0: never
 };
-// bit 20+f of a sub-step's returned mask: foot f's contact lies on the treadmill strip (foot primitive = 13 + 2f)
+// bit 24+f of a sub-step's returned mask: foot f's contact lies on the treadmill strip (foot primitive = 13 + 2f)
 SD int strip_feet_bits(int smask) {
-  return (((smask >> 13) & 1) << 20) | (((smask >> 15) & 1) << 21) | (((smask >> 17) & 1) << 22) | (((smask >> 19) & 1) << 23);
+  return (((smask >> 13) & 1) << 24) | (((smask >> 15) & 1) << 25) | (((smask >> 17) & 1) << 26) | (((smask >> 19) & 1) << 27);
 }
 
 template <typename T, int NQ> struct PhysState {
@@ -197,6 +199,12 @@ template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius) {
   T s = radius / sqrt(dx * dx + dz * dz + T(DISC_EPS2));
   return C + R.c0 * (dx * s) + R.c2 * (dz * s);
 }
+// the same for a disc about the link's x axis (shoulder housings)
+template <typename T> SD V3<T> disc_point_x(const M3<T>& R, V3<T> C, T radius) {
+  T dy = -R.c1.z, dz = -R.c2.z;                       // world-down expressed in the link's y,z
+  T s = radius / sqrt(dy * dy + dz * dz + T(DISC_EPS2));
+  return C + R.c1 * (dy * s) + R.c2 * (dz * s);
+}
 
 // sin/cos of a bounded angle (|x| < ~1e3: joint angles are limited to +-10 rad).  fp32: 3-constant
 // Cody-Waite reduction by pi/2 + minimax polynomials on [-pi/4, pi/4] (~30 VALU, <= 1 ulp), instead
@@ -245,12 +253,17 @@ SD void leg_frames(const M3<T>& R0, const T* sn, const T* cs, F&& f) {
 
 // knee and foot support points of leg L (relative to the base origin)
 template <typename T, int ROBOT, int L>
-SD void leg_prim_points(const M3<T>& R0, const T* sn, const T* cs, V3<T>& kneeP, V3<T>& footP) {
+SD void leg_prim_points(const M3<T>& R0, const T* sn, const T* cs, V3<T>& kneeP, V3<T>& footP, V3<T>& shP) {
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   constexpr int L0 = 1 + L * (NJ + 1);
   leg_frames<T, ROBOT, L>(R0, sn, cs, [&](auto kc, const M3<T>& R, V3<T> o, V3<T>) {
     constexpr int k = decltype(kc)::value;
+    if constexpr (RB::SHOULDER && k == 0) {  // shoulder housing: disc about x on the HAA link
+      constexpr solorl_prim_data PR = RB::MD.prims[20 + L];
+      static_assert(PR.link == L0 && PR.axis == 0, "shoulder primitive layout");
+      shP = disc_point_x(R, addc(o, R, PR.center[0], PR.center[1], PR.center[2]), T(PR.radius));
+    }
     if constexpr (k == NJ - 2) {  // knee disc sits on the upper leg
       constexpr solorl_prim_data PR = RB::MD.prims[12 + 2 * L];
       static_assert(PR.link == L0 + k && PR.axis == 1, "knee primitive layout");
@@ -291,7 +304,7 @@ template <typename T, int ROBOT> struct SubCtx {
   T tau[NQ];
   T sn[NQ], cs[NQ];
   M3<T> R0;
-  V3<T> kneeP[4], footP[4];
+  V3<T> kneeP[4], footP[4], shP[4];
   T dist[NPRIM];
   int mask, nc, nlim_total, nlim;
   int smask; T tmy;                // treadmill: primitives whose support point lies on the strip; the strip's centre line
@@ -300,7 +313,7 @@ template <typename T, int ROBOT> struct SubCtx {
   int limoff[4];                   // team mode: first joint-limit slot of each leg
   LegResp<T, NJ> LR[4];
   SV<T> ub; T qds[NQ];
-  SV<T> w; T y[4][3]; T lam_n[8];
+  SV<T> w; T y[4][3]; T lam_n[12];   // (lane mode: normal impulses of primitives 12..23)
   T lamp[NPRIM];                   // team mode: warm-start impulse cache, held in LDS across the sub-steps of a step
   // team mode, env logic (solorl_hip.hip step_team): the env's scalars in HBM field order (goal 2, potential, progress, goals,
   // env goals, reward-term sums 5, previous xy 2, treadmill centre line), its counters (timestep, contact mask, rng, snapshot
@@ -370,9 +383,15 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
   });
   static_for<4>([&](auto lc) {
     constexpr int L = decltype(lc)::value;
-    V3<T> kneeP, footP;
-    leg_prim_points<T, ROBOT, L>(R0, sn, cs, kneeP, footP);
-    C.kneeP[L] = kneeP; C.footP[L] = footP;
+    V3<T> kneeP, footP, shP = mk(T(0), T(0), T(0));
+    leg_prim_points<T, ROBOT, L>(R0, sn, cs, kneeP, footP, shP);
+    C.kneeP[L] = kneeP; C.footP[L] = footP; C.shP[L] = shP;
+    if constexpr (RB::SHOULDER) {
+      constexpr double ms_ = RB::MD.prims[20 + L].margin;
+      dist[20 + L] = st.pos.z + shP.z;
+      if (dist[20 + L] < T(ms_)) mask |= 1 << (20 + L);
+      if (pp.tm_on && fabs(ty + shP.y) <= pp.tm_hw) smask |= 1 << (20 + L);
+    } else dist[20 + L] = T(1);
     dist[12 + 2 * L] = st.pos.z + kneeP.z; dist[13 + 2 * L] = st.pos.z + footP.z;
     constexpr double mk_ = RB::MD.prims[12 + 2 * L].margin, mf_ = RB::MD.prims[13 + 2 * L].margin;   // (constexpr: no run-time model loads)
     if (dist[12 + 2 * L] < T(mk_)) mask |= 1 << (12 + 2 * L);
@@ -543,17 +562,17 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
     }
   });
   C.nlim = nlim;
-  // contact rows of this leg's primitives: knee (chain depth NJ-1) and foot (depth NJ)
+  // contact rows of this leg's primitives: knee (chain depth NJ-1), foot (depth NJ) and, Solo12, the shoulder housing (depth 1)
   const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
-  static_for<2>([&](auto ic) {
+  static_for<(RB::SHOULDER ? 3 : 2)>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    constexpr int p = 12 + 2 * L + i;
-    constexpr int DEPTH = i == 0 ? NJ - 1 : NJ;
+    constexpr int p = i < 2 ? 12 + 2 * L + i : 20 + L;
+    constexpr int DEPTH = i == 0 ? NJ - 1 : (i == 1 ? NJ : 1);
     constexpr solorl_prim_data PR = RB::MD.prims[p];
     if ((mask >> p) & 1) {
       const int cidx = __popc(mask & ((1 << p) - 1));
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
-      const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
+      const V3<T> P = i == 0 ? C.kneeP[L] : (i == 1 ? C.footP[L] : C.shP[L]);
       const T pen = C.dist[p] + pp.slop;
       const T lam0 = pp.warm * lam_prev[(unsigned)p * nstride];
       static_for<3>([&](auto dc) {
@@ -726,20 +745,21 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       }
     }
   });
-  // contact rows of this leg's primitives: knee (chain depth NJ-1) and foot (depth NJ)
+  // contact rows of this leg's primitives: knee (chain depth NJ-1), foot (depth NJ) and, Solo12, the shoulder housing (depth 1)
   const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
-  static_for<2>([&](auto ic) {
+  static_for<(RB::SHOULDER ? 3 : 2)>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    constexpr int DEPTH = i == 0 ? NJ - 1 : NJ;
-    const int p = 12 + 2 * L + i;
+    constexpr int DEPTH = i == 0 ? NJ - 1 : (i == 1 ? NJ : 1);
+    constexpr int P0 = i < 2 ? 12 + i : 20, PS = i < 2 ? 2 : 1;        // this primitive of leg L: P0 + PS * L
+    const int p = P0 + PS * L;
     if ((mask >> p) & 1) {
       const int cidx = __popc(mask & ((1 << p) - 1));
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
-      const V3<T> P = i == 0 ? C.kneeP[L] : C.footP[L];
+      const V3<T> P = i == 0 ? C.kneeP[L] : (i == 1 ? C.footP[L] : C.shP[L]);
       const T pen = C.dist[p] + pp.slop;
       const T lam0 = pp.warm * C.lamp[p];
-      const T fric = SEL4(T, lsg, RB::MD.prims[12 + i].friction, RB::MD.prims[14 + i].friction, RB::MD.prims[16 + i].friction,
-                          RB::MD.prims[18 + i].friction) * (((C.smask >> p) & 1) ? pp.tm_mu : T(1));
+      const T fric = SEL4(T, lsg, RB::MD.prims[P0].friction, RB::MD.prims[P0 + PS].friction, RB::MD.prims[P0 + 2 * PS].friction,
+                          RB::MD.prims[P0 + 3 * PS].friction) * (((C.smask >> p) & 1) ? pp.tm_mu : T(1));
       static_for<3>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
@@ -970,7 +990,7 @@ SNI void phase_pgs(CH ch, int iterations, T resid_thr, const LDS lds) {
 #pragma unroll
     for (int k = 0; k < 3; k++) C.y[l][k] = yl[(l * 3 + k) * LN];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < 12; i++) {
     const int p = 12 + i;
     C.lam_n[i] = ((C.mask >> p) & 1) ? lds.A(nlt + __popc(C.mask & ((1 << p) - 1)), R_::A_LAM) : T(0);
   }
@@ -1099,12 +1119,15 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
 #define PRIMC(i, f) SEL4(T, lsg, RB::MD.prims[12 + (i)].f, RB::MD.prims[14 + (i)].f, RB::MD.prims[16 + (i)].f, RB::MD.prims[18 + (i)].f)
     M3<T> Rp = R0;
     V3<T> op = mk(T(0), T(0), T(0));
-    V3<T> kneeP = op, footP = op;
+#define SHC(f) SEL4(T, lsg, RB::MD.prims[20].f, RB::MD.prims[21].f, RB::MD.prims[22].f, RB::MD.prims[23].f)
+    V3<T> kneeP = op, footP = op, shP = op;
     static_for<NJ>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       constexpr int AX = RB::MD.links[1 + k].axis[0] != 0.0 ? 0 : 1;   // same for all legs
       const V3<T> o = op + mul(Rp, mk(LEGC(k, jorigin[0]), LEGC(k, jorigin[1]), LEGC(k, jorigin[2])));
       const M3<T> R = rot_axis<AX>(Rp, C.cs[L * NJ + k], C.sn[L * NJ + k]);
+      if constexpr (RB::SHOULDER && k == 0)   // shoulder housing: disc about x on the HAA link (Solo12)
+        shP = disc_point_x(R, o + mul(R, mk(SHC(center[0]), SHC(center[1]), SHC(center[2]))), SHC(radius));
       if constexpr (k == NJ - 2)   // knee disc sits on the upper leg
         kneeP = disc_point(R, o + mul(R, mk(PRIMC(0, center[0]), PRIMC(0, center[1]), PRIMC(0, center[2]))), PRIMC(0, radius));
       if constexpr (k == NJ - 1)   // foot: fixed child of the last link, primitive centred on its origin
@@ -1120,6 +1143,14 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
       if (fabs(ty + kneeP.y) <= pp.tm_hw) sbits |= 1 << (12 + 2 * L);
       if (fabs(ty + footP.y) <= pp.tm_hw) sbits |= 1 << (13 + 2 * L);
     }
+    if constexpr (RB::SHOULDER) {
+      C.shP[L] = shP;
+      const T ds = pz + shP.z;
+      C.dist[20 + L] = ds;
+      if (ds < SHC(margin)) bits |= 1 << (20 + L);
+      if (pp.tm_on && fabs(ty + shP.y) <= pp.tm_hw) sbits |= 1 << (20 + L);
+    } else C.dist[20 + L] = T(1);              // (no such primitive: never in contact, never ranked)
+#undef SHC
 #undef PRIMC
 #undef LEGC
   } else if (valid) {

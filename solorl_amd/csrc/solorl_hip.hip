@@ -166,8 +166,8 @@ SD void current_state(const Env<T, Robot<ROBOT>::NQ>& E, int task, T (&cs)[DMAX]
 #pragma unroll
   for (int j = 0; j < NQ; j++) { cs[10 + j] = E.ps.q[j] * T(0.1); cs[10 + NQ + j] = E.ps.qd[j] * T(0.01); }   // (/10, /100: solo.py:208-209)
 #pragma unroll
-  for (int f = 0; f < 4; f++)    // solo.py:310-323: plane contacts only -- a foot on the treadmill strip (bit 20+f) is not reported
-    cs[10 + 2 * NQ + f] = (((E.mask >> (13 + 2 * f)) & 1) && !((E.mask >> (20 + f)) & 1)) ? T(1) : T(0);
+  for (int f = 0; f < 4; f++)    // solo.py:310-323: plane contacts only -- a foot on the treadmill strip (bit 24+f) is not reported
+    cs[10 + 2 * NQ + f] = (((E.mask >> (13 + 2 * f)) & 1) && !((E.mask >> (24 + f)) & 1)) ? T(1) : T(0);
   if (task == SOLORL_TASK_POINTGOAL) {
     cs[14 + 2 * NQ] = E.ps.pos.x * T(0.5); cs[15 + 2 * NQ] = E.ps.pos.y * T(0.5);
     cs[16 + 2 * NQ] = E.goal[0] * T(0.5); cs[17 + 2 * NQ] = E.goal[1] * T(0.5);
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
   const int t = threadIdx.x, nt = blockDim.x;
   const int chunk = (N + nt - 1) / nt, lo = t * chunk, hi = lo + chunk < N ? lo + chunk : N;
   int c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = lo; i < hi; i++) { int k = __popc(si[SX(I_MASK, (idx_t)i, NI)] & 0xFFFFF); k = k > 8 ? 8 : k; c[k]++; }
+  for (int i = lo; i < hi; i++) { int k = __popc(si[SX(I_MASK, (idx_t)i, NI)] & 0xFFFFFF); k = k > 8 ? 8 : k; c[k]++; }
 #pragma unroll
   for (int k = 0; k < 9; k++) cnt[t][k] = c[k];
   __syncthreads();
@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(256) sort_perm_kernel(const int* __restrict__ 
 #pragma unroll
   for (int k = 0; k < 9; k++) off[k] = base[k] + cnt[t][k];
   for (int i = lo; i < hi; i++) {
-    int k = __popc(si[SX(I_MASK, (idx_t)i, NI)] & 0xFFFFF); k = k > 8 ? 8 : k;
+    int k = __popc(si[SX(I_MASK, (idx_t)i, NI)] & 0xFFFFFF); k = k > 8 ? 8 : k;
     int d = 0;
 #pragma unroll
     for (int q = 0; q < 9; q++) if (q == k) d = off[q]++;

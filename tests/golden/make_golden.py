@@ -134,7 +134,7 @@ def make_walk():
         a = walk_action(t)[None]
         o.step(a); p.step(a)
         st = o.get_state(0)
-        q.append(np.array(st.q)); z.append(st.pos[2]); nc.append(bin(st.contact_mask & 0xFFFFF).count("1"))
+        q.append(np.array(st.q)); z.append(st.pos[2]); nc.append(bin(st.contact_mask & 0xFFFFFF).count("1"))
         pert.append(np.abs(np.array(st.q) - np.array(p.get_state(0).q)).max())
     np.savez(os.path.join(HERE, "walk_torque_traj.npz"), q=np.array(q), z=np.array(z), ncontacts=np.array(nc),
              pert_dq=np.array(pert), oracle_self_horizon=divergence_horizon(pert))

@@ -35,7 +35,7 @@ def test_default_config_matches_python_mirror(lib):
             assert lib.solorl_default_config(C.byref(c), robot, task) == 0
             assert bytes(c) == bytes(default_config(robot, task))
     assert C.sizeof(SoloConfig) == 14 * 4 + 17 * 8
-    assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 20 + 2 * 42 + 2 + 4 + 5 + 1) + 4 * 4
+    assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 24 + 2 * 42 + 2 + 4 + 5 + 1) + 4 * 4
 
 
 def test_error_convention(lib):
@@ -94,7 +94,7 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
     assert len(hot) >= 10, sorted(st)[:5]          # 5 phases x 2 robots
     for n in hot:
         assert st[n]["scratch"] <= 2, (n, st[n])   # (leaf phases: at most one register saved around the body)
-        assert st[n]["flat"] <= 11, (n, st[n])     # phase_leg_rt reads PhysParams fields (9 + the treadmill friction, twice) through its reference argument
+        assert st[n]["flat"] <= 13, (n, st[n])     # phase_leg_rt reads PhysParams fields (9 + the treadmill friction per leg primitive) through its reference argument
         assert st[n]["global"] == 0, (n, st[n])
     # the 17 specialised sweeps: whatever their register pressure (the heaviest save callee-saved registers to scratch
     # around the body now that the kernel is held to 256 registers for two wavefronts per SIMD), the sweep LOOP itself

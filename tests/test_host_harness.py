@@ -60,8 +60,8 @@ def test_contact_substeps_resynced(robot, n, treadmill, urdf_inertia):
         harness_py.substep(h64, c, False); harness_py.substep(h32, c, True)
         a = o.get_state(0)
         assert a.contact_mask == h64.contact_mask
-        saw_contacts += bin(a.contact_mask & 0xFFFFF).count("1") > 0
-        strip += (a.contact_mask >> 20) != 0
+        saw_contacts += bin(a.contact_mask & 0xFFFFFF).count("1") > 0
+        strip += (a.contact_mask >> 24) != 0
         e64.append(np.abs(state_vec(a, n) - state_vec(h64, n)).max())
         e32.append(np.abs(state_vec(a, n) - state_vec(h32, n)).max())
     e64, e32 = np.array(e64), np.array(e32)
@@ -111,14 +111,15 @@ def test_standing_trajectory_fp32_within_1e3_rad():
 def test_walk_torque_parity_input_divergence_horizon():
     """SURVEY.md 8(d) parity input verbatim (Solo12 walk, torque control, K = 8, a = 0.5 sin(2 pi t/60 + j pi/6), default
     torque lifetime, termination off).  1.5 N.m on a 2.5 kg robot folds it to the ground within 20 control steps and it
-    thrashes there: the fp64 oracle ITSELF, perturbed by 1e-12 rad, leaves the 1e-3 rad band after 61 steps
+    thrashes there: the fp64 oracle ITSELF, perturbed by 1e-12 rad, leaves the 1e-3 rad band after ~60 steps
     (fixture `oracle_self_horizon`).  Divergence horizon = first step with max |dq| > 1e-3 rad vs the fixture:
     the kernel math in fp64 holds as long as the oracle's own horizon, in fp32 (eps 6e-8 instead of 1e-12) 17 steps."""
     import os
     from tests.golden.make_golden import walk_cfg, walk_action, divergence_horizon
     from tests.util import GOLDEN
     g = np.load(os.path.join(GOLDEN, "walk_torque_traj.npz"))
-    assert int(g["oracle_self_horizon"]) == divergence_horizon(g["pert_dq"]) == 61
+    self_h = int(g["oracle_self_horizon"])
+    assert self_h == divergence_horizon(g["pert_dq"]) and 50 <= self_h <= 70          # (58 with the round-2 primitive set)
     c = walk_cfg()
     o = Oracle(c, 1, seed=1); o.reset()
     h = {True: clone(o.get_state(0)), False: clone(o.get_state(0))}
@@ -135,7 +136,7 @@ def test_walk_torque_parity_input_divergence_horizon():
                 harness_py.substep(h[use_float], c, use_float)
             dq[use_float].append(np.abs(np.array(h[use_float].q) - g["q"][t]).max())
     h64, h32 = divergence_horizon(dq[False]), divergence_horizon(dq[True])
-    assert h64 >= 55, h64
+    assert h64 >= self_h - 8, (h64, self_h)
     assert h32 >= 12, h32
     assert max(dq[False][:10]) < 1e-11 and max(dq[True][:10]) < 5e-4          # before the fall: rounding only
 

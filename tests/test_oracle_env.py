@@ -188,7 +188,7 @@ def test_treadmill_side_is_redrawn_at_reset_and_hides_feet_from_the_sensor():
         assert all((s.contact_mask >> (13 + 2 * f)) & 1 for f in range(4))
         feet = list(obs[i][34:38])                                     # FL FR HL HR
         assert feet == ([0, 1, 0, 1] if ys[i] > 0 else [1, 0, 1, 0])
-        assert ((s.contact_mask >> 20) & 0xF) == (0b0101 if ys[i] > 0 else 0b1010)
+        assert ((s.contact_mask >> 24) & 0xF) == (0b0101 if ys[i] > 0 else 0b1010)
     # an episode end redraws the side from the env's own stream
     c2 = mk(ROBOT_SOLO12, TASK_WALK, use_treadmill=1, episode_length=1)
     o = Oracle(c2, 256, seed=6); o.reset()

@@ -3,9 +3,11 @@ engine leaves out change?  Bullet collides the convex hull of every link; oracle
 per knee and 12 base points.  Left out: the lower legs (their hull is a 7.8 mm half-width rod between the 22 mm knee disc
 and the 16 mm foot disc -- it cannot touch the plane before both of those do) and the Solo12 shoulder housings (widest
 section 30.5 mm about the HAA axis, friction 0.5, protruding <= 5.5 mm below the base's belly plate when rolled).
-ORACLE_K6_SHOULDERS=1 adds the housings to the oracle as four disc primitives; this test keeps the measurement honest:
-under a random policy they are in contact in roughly a tenth of the states and shift the termination count by a few
-per cent -- small, but above the seed-to-seed scatter, so they are listed as a known deviation of the engine."""
+The measurement (round 2, 512 envs x 300 steps, 3 seeds) found the housings in contact in 9 % of the random-policy states
+and shifting the termination count by -1.3 % +- 0.7 % (a cruder, maximum-radius disc: -3.2 %) -- at the edge of the
+seed-to-seed scatter -- and they were added to the model table
+(primitives 20..23, tools/compile_model.py: least-squares circle of the hull's support function about the link's x axis)
+and to the engine.  ORACLE_NO_SHOULDERS=1 drops them from the oracle again; this test keeps the measurement reproducible."""
 import os
 
 import numpy as np
@@ -15,13 +17,13 @@ from oracle.oracle_py import Oracle
 
 
 def rollout(shoulders, seed, N=256, T=240):
-    if shoulders:
-        os.environ["ORACLE_K6_SHOULDERS"] = "1"
+    if not shoulders:
+        os.environ["ORACLE_NO_SHOULDERS"] = "1"
     try:
         c = default_config(ROBOT_SOLO12, TASK_WALK); c.num_history_stack = 1
         o = Oracle(c, N, seed=seed, threads=min(8, os.cpu_count() or 1))
     finally:
-        os.environ.pop("ORACLE_K6_SHOULDERS", None)
+        os.environ.pop("ORACLE_NO_SHOULDERS", None)
     o.reset()
     acts = np.random.default_rng(seed + 100).uniform(-1, 1, size=(32, N, 12))
     done = z = sh = tot = 0
@@ -31,7 +33,7 @@ def rollout(shoulders, seed, N=256, T=240):
         done += int(d.sum()); z += float(obs[:, 0].mean()); rew.append(r[d == 0])
         if t % 8 == 0:
             for i in range(0, N, 4):
-                tot += 1; sh += (o.get_state(i).contact_mask >> 24) != 0
+                tot += 1; sh += ((o.get_state(i).contact_mask >> 20) & 0xF) != 0
     return dict(done=done, z=z / T, med_rew=float(np.median(np.concatenate(rew))), shoulder_frac=sh / tot)
 
 
@@ -39,9 +41,9 @@ def test_shoulder_housings_effect_is_small_but_measurable():
     base = [rollout(0, s) for s in (1, 2)]
     with_ = [rollout(1, s) for s in (1, 2)]
     assert all(b["shoulder_frac"] == 0 for b in base)
-    assert all(0.03 < w["shoulder_frac"] < 0.3 for w in with_)            # measured 0.12 (512 envs x 300 steps, 3 seeds)
+    assert all(0.03 < w["shoulder_frac"] < 0.3 for w in with_)            # measured 0.09 (512 envs x 300 steps, 3 seeds)
     d0, d1 = np.mean([b["done"] for b in base]), np.mean([w["done"] for w in with_])
-    assert -0.10 < (d1 - d0) / d0 < 0.0                                   # measured -3.2 % (seed scatter 0.8 %)
+    assert -0.08 < (d1 - d0) / d0 < 0.03                                  # measured -1.3 % +- 0.7 % (seed scatter 0.8 %)
     for b, w in zip(base, with_):
         assert abs(w["med_rew"] - b["med_rew"]) < 0.15 * abs(b["med_rew"]) + 0.05     # measured -4 %
         assert abs(w["z"] - b["z"]) < 0.15 * b["z"]

@@ -307,7 +307,7 @@ def test_treadmill_configs_basic_yaml_vs_oracle(gpu_device):
             sg, so = env.get_state(i), orc.get_state(i)
             dq.append(np.abs(np.array(sg.q)[:8] - np.array(so.q)[:8]).max())
             mism += sg.contact_mask != so.contact_mask
-            strip_seen += (sg.contact_mask >> 20) != 0
+            strip_seen += (sg.contact_mask >> 24) != 0
     dq = np.array(dq)
     assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 1e-3, (np.median(dq), np.percentile(dq, 90))
     assert mism <= 0.02 * len(dq) and strip_seen > 0.3 * len(dq)

@@ -142,6 +142,24 @@ def compile_robot(desc_dir, urdf_name):
         hf = hulls[leg + "_FOOT"]
         prims.append(dict(link=foot, kind="disc", center=[0.0, 0.0, 0.0], axis=1,
                           radius=float(np.hypot(hf[:, 0], hf[:, 2]).max())))
+    # Solo12 shoulder housings (K6, measured in tests/test_oracle_k6.py: -3 % terminations without them): one disc about the
+    # link's x axis (= the HAA axis direction).  The hull's support function in the directions perpendicular to x,
+    # h(theta) = max_v (v_y cos theta + v_z sin theta), is fitted by a circle yc cos + zc sin + r in the least-squares
+    # sense; the disc sits at the x of the widest section.  Appended AFTER the 20 primitives both robots share, so the
+    # knee / foot indices (12 + 2 leg, 13 + 2 leg) stay what every consumer assumes.
+    for leg in LEGS:
+        name = leg + "_SHOULDER"
+        if name not in hulls:
+            continue
+        hs = hulls[name]
+        th = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+        h = (hs[:, 1:2] * np.cos(th) + hs[:, 2:3] * np.sin(th)).max(axis=0)
+        A = np.stack([np.cos(th), np.sin(th), np.ones_like(th)], axis=1)
+        (yc, zc, r), *_ = np.linalg.lstsq(A, h, rcond=None)
+        rad = np.hypot(hs[:, 1] - yc, hs[:, 2] - zc)
+        xw = float(hs[np.argmax(rad), 0])
+        clean = lambda v: 0.0 if abs(v) < 1e-9 else round(float(v), 9)     # (the four legs' fits then mirror exactly)
+        prims.append(dict(link=index[name], kind="disc", center=[clean(xw), clean(yc), clean(zc)], axis=0, radius=clean(r)))
     for p in prims:
         p["friction"] = links[p["link"]]["friction"] * 1.0   # x plane.urdf lateral friction 1.0 [K6]
         p["margin"] = links[p["link"]]["margin"]
@@ -172,7 +190,7 @@ def emit_header(models, path):
     o.append("#endif")
     o.append("#define SOLORL_MAX_LINKS 17")
     o.append("#define SOLORL_MAX_DOF 12")
-    o.append("#define SOLORL_MAX_PRIMS 20")
+    o.append("#define SOLORL_MAX_PRIMS 24")
     o.append("typedef struct solorl_link_data {")
     o.append("  int parent; int jtype; /* -1 base, 0 revolute, 1 fixed */ int dof; /* index into q or -1 */")
     o.append("  double axis[3]; double jorigin[3]; double com[3]; double mass;")
@@ -189,7 +207,7 @@ def emit_header(models, path):
     for m in models:
         dof_of = {l: i for i, l in enumerate(m["dof_links"])}
         foot_prims = [i for i, p in enumerate(m["prims"]) if p["link"] in m["foot_links"]]
-        assert len(foot_prims) == 4 and len(m["prims"]) <= 20
+        assert len(foot_prims) == 4 and len(m["prims"]) <= 24
         o.append("SOLORL_MODEL_CONST solorl_model_data SOLORL_MODEL_%s = {" % m["name"].upper())
         o.append('  "%s", %d, %d, %d, %s,' % (m["name"], m["nlinks"], m["ndof"], len(m["prims"]),
                                             c_array(foot_prims, "%d")))
