@@ -49,11 +49,14 @@ class GraphedRollout:
     def _body(self):
         st = self.storage
         assert st.step == 0, "graphed rollouts start at storage step 0"
-        for step in range(self.T):
-            with torch.no_grad():
-                value, action, logp = self.ac.act(st.obs[step])
-            obs, reward, done, info = self.envs.step_inplace(action.contiguous())
-            st.append(obs, action, logp, value, reward.unsqueeze(-1), (1.0 - done.float()).unsqueeze(-1))
+        # the arithmetic of train.rollout() with every result written where it is stored: the policy's outputs and the engine's
+        # observations / rewards go straight into the storage rows (the C ABI takes caller-owned pointers), masks = 1 - done in
+        # one launch -- 19 launches per step instead of 35, and launches are what a step costs besides the env kernel
+        one = torch.ones((), device=st.device)
+        for t in range(self.T):
+            self.ac.act_into(st.obs[t], st.value_preds[t], st.actions[t], st.action_log_probs[t])
+            _, _, done, _ = self.envs.step_inplace(st.actions[t], obs_out=st.obs[t + 1], rew_out=st.rewards[t])
+            torch.sub(one, done, out=st.masks[t + 1].view(-1))
 
     def _capturable(self):
         # contact-count sorting (opt-in, SOLORL_SORT=1) ping-pongs two state buffers on the host side of
@@ -87,8 +90,10 @@ class GraphedPPO(PPO):
                          l2_coef=l2_coef, max_grad_norm=max_grad_norm, use_clipped_value_loss=use_clipped_value_loss)
         self.fused_loss = fused_loss
         dev = next(actor_critic.parameters()).device
+        # (fused: one multi-tensor launch per optimizer step instead of a dozen -- a captured mini-batch step is ~100 launches of a
+        # few microseconds each, so launches are what it costs)
         self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=torch.tensor(float(lr), device=dev),
-                                          weight_decay=l2_coef, capturable=True)
+                                          weight_decay=l2_coef, capturable=True, fused=True)
         self._built_for = None
 
     # ---- capture
@@ -132,7 +137,10 @@ class GraphedPPO(PPO):
 
         def opt_step():
             if self.max_grad_norm is not None:
-                nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+                # clip_grad_norm_ (agents/ppo/ppo.py:75-76) on the flat bucket every .grad is a view of: the 2-norm of the
+                # per-tensor norms is the norm of the concatenation
+                flat = self.bucket.flat
+                flat.mul_((self.max_grad_norm / (flat.norm() + 1e-6)).clamp(max=1.0))
             self.optimizer.step()
 
         # warm-up on a side stream (allocator, autograd and optimizer state), then put everything back

@@ -15,6 +15,46 @@ import torch
 import torch.nn as nn
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b whose weight gradient is reduced in independent slices of the batch.
+
+    A PPO mini-batch is tens of thousands of rows through 64-wide layers: dW = g^T x is a (64 x 76) product with a
+    32 768-long reduction -- two or three output tiles, i.e. two or three workgroups on a 256-CU device (measured on an
+    MI355X: 133 us per layer, two thirds of a mini-batch step).  Cut into S slices it is one batched GEMM over S x as many
+    workgroups plus a small sum; the arithmetic is the same sum in a different order."""
+    SLICE_ROWS = 512
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g.mm(w) if ctx.needs_input_grad[0] else None
+        m, r = x.shape[0], _LinearSplitK.SLICE_ROWS
+        s = m // r
+        if s >= 2:
+            m0 = s * r
+            gw = torch.bmm(g[:m0].reshape(s, r, -1).transpose(1, 2), x[:m0].reshape(s, r, -1)).sum(0)
+            if m0 < m:
+                gw = gw + g[m0:].t().mm(x[m0:])
+        else:
+            gw = g.t().mm(x)
+        return gx, gw, g.sum(0)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameter names, same forward) with the split reduction above for training batches."""
+    SPLIT_MIN_ROWS = 4096
+
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= Linear.SPLIT_MIN_ROWS and torch.is_grad_enabled() and self.bias is not None:
+            return _LinearSplitK.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def ortho_(linear, gain=math.sqrt(2.0)):
     """agents/utils.py:120-131 (init_layer): orthogonal weights with gain sqrt(2), zero bias."""
     nn.init.orthogonal_(linear.weight.data, gain=gain)
@@ -28,9 +68,9 @@ class MLPBase(nn.Module):
         super().__init__()
         self.output_size = hidden_size
         h = hidden_size
-        self.features = nn.Sequential(ortho_(nn.Linear(num_inputs, h)), nn.Tanh(), ortho_(nn.Linear(h, h)), nn.Tanh())
-        self.critic = nn.Sequential(ortho_(nn.Linear(num_inputs, h)), nn.Tanh(), ortho_(nn.Linear(h, h)), nn.Tanh(),
-                                    ortho_(nn.Linear(h, 1)))
+        self.features = nn.Sequential(ortho_(Linear(num_inputs, h)), nn.Tanh(), ortho_(Linear(h, h)), nn.Tanh())
+        self.critic = nn.Sequential(ortho_(Linear(num_inputs, h)), nn.Tanh(), ortho_(Linear(h, h)), nn.Tanh(),
+                                    ortho_(Linear(h, 1)))
 
     def forward(self, x):
         return self.critic(x), self.features(x)
@@ -39,7 +79,7 @@ class MLPBase(nn.Module):
 class DiagGaussianHead(nn.Module):
     def __init__(self, num_inputs, num_outputs):
         super().__init__()
-        self.mean = ortho_(nn.Linear(num_inputs, num_outputs))
+        self.mean = ortho_(Linear(num_inputs, num_outputs))
         self.logstd = nn.Parameter(torch.zeros(num_outputs))
 
     def forward(self, feat):
@@ -78,6 +118,22 @@ class Policy(nn.Module):
         mean, logstd = self.pi_dist(feat)
         action = mean if deterministic else mean + torch.exp(logstd) * torch.randn_like(mean)
         return value, action, gaussian_log_prob(action, mean, logstd)
+
+    @torch.no_grad()
+    def act_into(self, inputs, value_out, action_out, logp_out, noise=None):
+        """`act` for rollout loops that own their buffers (ppo/storage.py): the same arithmetic written straight into
+        value_out [N,1], action_out [N,A] and logp_out [N,1] -- about half the launches of act() + three copies, which is what
+        a captured rollout step costs besides the env kernel.  `noise` (optional, [N,A]) replaces the standard-normal draw."""
+        c, f = self.base.critic, self.base.features
+        lin = lambda l, x, out=None: torch.addmm(l.bias, x, l.weight.t(), out=out)
+        lin(c[4], torch.tanh_(lin(c[2], torch.tanh_(lin(c[0], inputs)))), out=value_out)
+        mean = lin(self.pi_dist.mean, torch.tanh_(lin(f[2], torch.tanh_(lin(f[0], inputs)))))
+        logstd = self.pi_dist.logstd
+        if noise is None:
+            noise = torch.randn_like(mean)
+        torch.addcmul(mean, torch.exp(logstd), noise, out=action_out)
+        z = (action_out - mean).mul_(torch.exp(-logstd))
+        torch.sum(z.mul_(z).mul_(-0.5).sub_(logstd).sub_(_HALF_LOG_2PI), -1, keepdim=True, out=logp_out)
 
     def heads(self, inputs):
         """(value, mean, logstd): what the fused loss kernel (ppo/fused.py) consumes."""

@@ -153,19 +153,25 @@ class SoloVecEnv:
         t["done"] = self._done.clone()
         return self._obs.clone(), self._rew.clone().unsqueeze(-1), t["done"].float(), LazyInfos(t, t["done"])
 
-    def step_inplace(self, actions):
-        """Zero-copy variant for rollout loops: returns views of the engine-owned output buffers
-        (overwritten by the next step).  ``actions`` is handed to the kernel as a raw pointer, so it must already be
-        what the C ABI expects: float32, contiguous, [N, A], on this env's device (host-side checks only, capturable)."""
-        if not (actions.is_cuda and actions.device == self.device and actions.dtype == torch.float32
-                and actions.is_contiguous() and tuple(actions.shape) == (self.nenvs, self.act_dim)):
-            raise AssertionError("step_inplace needs a contiguous float32 [%d, %d] tensor on %s, got %s %s on %s" % (
-                self.nenvs, self.act_dim, self.device, actions.dtype, tuple(actions.shape), actions.device))
+    def _raw(self, name, x, shape):
+        """The C ABI takes raw pointers: `x` must already be float32, contiguous, of `shape`, on this env's device."""
+        if not (x.is_cuda and x.device == self.device and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == shape):
+            raise AssertionError("%s must be a contiguous float32 %s tensor on %s, got %s %s on %s" % (
+                name, list(shape), self.device, x.dtype, tuple(x.shape), x.device))
+        return C.c_void_p(x.data_ptr())
+
+    def step_inplace(self, actions, obs_out=None, rew_out=None):
+        """Zero-copy variant for rollout loops: returns views of the engine-owned output buffers (overwritten by the next
+        step) -- or writes observations [N, O] / rewards [N] or [N, 1] straight into caller-owned tensors such as rollout-storage
+        rows (the C ABI takes the caller's pointers anyway).  Host-side checks only, capturable in a HIP graph."""
+        a = self._raw("actions", actions, (self.nenvs, self.act_dim))
+        o = self._obs if obs_out is None else obs_out
+        r = self._rew if rew_out is None else rew_out
+        po = self._raw("obs_out", o, (self.nenvs, self.obs_dim))
+        pr = self._raw("rew_out", r, tuple(r.shape) if tuple(r.shape) in ((self.nenvs,), (self.nenvs, 1)) else (self.nenvs,))
         with torch.cuda.device(self.device):
-            _native.check(self.L.solorl_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()),
-                                             C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
-                                             C.byref(self._info_c), self._stream()))
-        return self._obs, self._rew, self._done, self._info
+            _native.check(self.L.solorl_step(self._h, a, po, pr, C.c_void_p(self._done.data_ptr()), C.byref(self._info_c), self._stream()))
+        return o, r, self._done, self._info
 
     def get_observation(self):
         with torch.cuda.device(self.device):

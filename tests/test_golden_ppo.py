@@ -2,6 +2,8 @@
 (tests/golden/make_golden_ppo.py)."""
 import os
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -82,3 +84,35 @@ def test_linear_lr_schedule():
         update_linear_schedule(opt, ep, 100, 2.5e-4)
         got.append(opt.param_groups[0]["lr"])
     assert got == pytest.approx(G["linear_schedule"], rel=1e-12)
+
+
+def test_split_reduction_linear_has_nn_linear_gradients():
+    """ppo/policy.py Linear: training batches take the sliced weight-gradient path; values and gradients are nn.Linear's
+    (float64: equal up to summation order), parameter names unchanged (checkpoints, agents/ppo/train.py:121-131)."""
+    from solorl_amd.ppo.policy import Linear
+    torch.manual_seed(3)
+    for m in (4096, 5000, 300):                         # whole slices / slices + remainder / below the threshold
+        a, b = Linear(7, 5).double(), torch.nn.Linear(7, 5).double()
+        b.load_state_dict(a.state_dict())
+        x = torch.randn(m, 7, dtype=torch.float64)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        wgt = torch.randn(m, 5, dtype=torch.float64)
+        ya, yb = a(xa), b(xb)
+        assert torch.allclose(ya, yb, rtol=0, atol=1e-14)
+        (ya * wgt).sum().backward(); (yb * wgt).sum().backward()
+        for ga, gb in ((a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad), (xa.grad, xb.grad)):
+            assert torch.allclose(ga, gb, rtol=1e-12, atol=1e-12)
+    assert list(Linear(3, 2).state_dict()) == ["weight", "bias"]
+
+
+def test_act_into_is_act():
+    """Policy.act_into (rollout loops writing into their storage rows) computes act()'s value / action / log-prob."""
+    torch.manual_seed(0)
+    pol = Policy((76,), Box(-np.ones(12), np.ones(12)), None, {"hidden_size": 64})
+    with torch.no_grad():
+        pol.pi_dist.logstd.normal_(0, 0.3)
+    x = torch.randn(50, 76)
+    torch.manual_seed(4); v, a, lp = pol.act(x)
+    vo, ao, lo = torch.empty(50, 1), torch.empty(50, 12), torch.empty(50, 1)
+    torch.manual_seed(4); pol.act_into(x, vo, ao, lo)
+    assert torch.allclose(v, vo, atol=1e-6) and torch.allclose(a, ao, atol=1e-6) and torch.allclose(lp, lo, atol=1e-5)

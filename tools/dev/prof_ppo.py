@@ -7,4 +7,4 @@ from solorl_amd.vec_env import SoloVecEnv
 dev = torch.device("cuda:0")
 cfg = default_config(ROBOT_SOLO12, TASK_WALK); cfg.num_history_stack = 1
 env = SoloVecEnv(cfg, 4096, device=dev, seed=1); env.reset()
-print(bench.ppo_leg(env, dev, 1, 64))
+print(bench.ppo_leg(env, dev, 1, int(os.environ.get("PPO_T", "400")), int(os.environ.get("PPO_EPOCHS", "1"))))
