@@ -16,6 +16,11 @@
  *                             400 sequential tiny torch ops per update in the reference)
  *   solorl_ppo_loss        <- agents/ppo/ppo.py:52-74 (clipped surrogate + clipped value loss) with the Gaussian
  *                             log-prob of agents/ppo/policy.py:51-58,171-173: ~60 elementwise torch kernels per mini-batch
+ *   solorl_policy_act      <- agents/ppo/policy.py:33-49 (Policy.act on the MLPBase of :62-81): value, sampled action, log-prob
+ *   solorl_ppo_grad_stage1 <- agents/ppo/ppo.py:46-74 for one mini-batch: storage.py:57-71 gather, policy.py:51-58
+ *                             evaluate_actions, the clipped losses, and autograd's back-propagation down to every layer's
+ *                             pre-activation gradient (what `loss.backward()` computes before the weight-gradient GEMMs)
+ *   solorl_ppo_grad_stage2 <- the weight-gradient products of that backward pass, written into the parameters' gradients
  *   solorl_get_state / solorl_set_state : no reference counterpart (parity-test hooks)
  *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
  *
@@ -185,6 +190,59 @@ int solorl_compute_returns(const float* rewards /* [T*N] */, float* value_preds 
 int solorl_ppo_loss(const float* mean, const float* logstd, const float* values, const float* action, const float* old_logp,
                     const float* adv, const float* vpred, const float* ret, int m, int A, float clip, float value_coef,
                     int clipped_value, float* grad_mean, float* grad_values, float* partials, int device_id, void* stream);
+
+/* Parameters of the reference's MLP actor-critic in PyTorch layout (nn.Linear weight = [out][in], row-major), device pointers:
+ * base.critic.{0,2,4}, base.features.{0,2}, pi_dist.mean, pi_dist.logstd (agents/ppo/policy.py:62-81,138-148).  The kernels
+ * are built for hidden = 64 and (obs_dim, act_dim) in {(76,12), (84,12), (60,8), (68,8)} -- one history level; other shapes
+ * return SOLORL_ERR_INVALID and the caller keeps its framework path. */
+typedef struct solorl_policy_params {
+  int obs_dim, act_dim, hidden, reserved0;
+  const float *critic_w0, *critic_b0, *critic_w1, *critic_b1, *critic_w2, *critic_b2;
+  const float *actor_w0, *actor_b0, *actor_w1, *actor_b1, *mean_w, *mean_b, *logstd;
+} solorl_policy_params;
+
+/* Policy.act for n observation rows: value_out[n], action_out[n][A] = mean + exp(logstd) * noise (noise[n][A]: the caller's
+ * standard-normal draw; NULL = deterministic, action = mean), logp_out[n] = log N(action; mean, exp(logstd)) summed over A. */
+int solorl_policy_act(const solorl_policy_params* p, const float* obs /* [n][obs_dim] */, const float* noise, int n, float* value_out,
+                      float* action_out, float* logp_out, int device_id, void* stream);
+
+/* One PPO mini-batch, everything of forward + backward except the weight-gradient GEMMs.  Sample r of the mini-batch is
+ * row perm[*offset + r] of the rollout arrays (perm, offset: device memory, so a captured launch needs no host argument). */
+typedef struct solorl_ppo_batch {
+  const float *obs /* [n][obs_dim] */, *actions /* [n][A] */, *old_logp, *adv, *vpred, *ret /* [n] each */;
+  const int64_t *perm, *offset;
+  int m;                       /* mini-batch rows */
+  int clipped_value;           /* ppo.py:61 use_clipped_value_loss */
+  float clip, value_coef;      /* ppo.py:56 clip_param; the value-loss coefficient is folded into the critic's gradient */
+} solorl_ppo_batch;
+/* Outputs, all [unit][m] (row index fastest): xt0 = gathered observations [obs_dim][m]; per net (c_ critic, a_ actor) the hidden
+ * activations xt1, xt2 [64][m], the pre-activation gradients g1, g2 [64][m] and the head-output gradient gh ([1][m] / [A][m]).
+ * Weight gradients are then G^T X products over the rows:  d W0 = g1 xt0^T, d W1 = g2 xt1^T, d Whead = gh xt2^T, biases = row
+ * sums of g.  partials [ceil(m/64)][3 + A]: per 64 rows (sum value loss, sum action loss, rows, sum d action-loss / d logstd_a);
+ * the entropy term of ppo.py:74 does not depend on the samples and is left to the caller. */
+typedef struct solorl_ppo_stage1 {
+  float *xt0, *c_xt1, *c_xt2, *c_g1, *c_g2, *c_gh, *a_xt1, *a_xt2, *a_g1, *a_g2, *a_gh, *partials;
+} solorl_ppo_stage1;
+int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch* batch, const solorl_ppo_stage1* work, int device_id,
+                           void* stream);
+
+/* Stage 2: the weight gradients d W = g x^T (+ biases) of all six layers from stage 1's arrays, and the step's bookkeeping.
+ * `out` names where each gradient goes (PyTorch layouts, e.g. views of one flat bucket), plus
+ *   loss_sums [3 + A]  += (sum value loss, sum action loss, rows, sum d action-loss / d logstd) of this mini-batch,
+ *   logstd_sum [1]     += sum_a logstd_a            (entropy = 0.5 + log sqrt(2 pi) + mean_a logstd_a, policy.py:56)
+ *   logstd             = sum d action-loss / d logstd - entropy_coef / A       (the complete gradient of ppo.py:74's loss)
+ *   scratch            >= ceil(m / 4096) * solorl_ppo_grad_count(obs_dim, act_dim) floats of working memory.
+ * Sums are taken in a fixed order: results are reproducible run to run. */
+typedef struct solorl_ppo_grads {
+  float *critic_w0, *critic_b0, *critic_w1, *critic_b1, *critic_w2, *critic_b2;
+  float *actor_w0, *actor_b0, *actor_w1, *actor_b1, *mean_w, *mean_b, *logstd;
+  float *loss_sums, *logstd_sum, *scratch;
+  float entropy_coef, reserved0;
+} solorl_ppo_grads;
+int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage1* work, int m, const solorl_ppo_grads* out, int device_id,
+                           void* stream);
+/* number of weight + bias elements of the actor-critic except logstd (one scratch chunk) */
+int solorl_ppo_grad_count(int obs_dim, int act_dim);
 
 const char* solorl_last_error(void);
 const char* solorl_version(void);

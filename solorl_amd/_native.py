@@ -15,7 +15,28 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/solorl.h declares
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
            "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state",
-           "solorl_compute_returns", "solorl_ppo_loss", "solorl_last_error", "solorl_version")
+           "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_last_error", "solorl_version")
+
+
+class PolicyParams(C.Structure):            # solorl_policy_params
+    _fields_ = [("obs_dim", C.c_int), ("act_dim", C.c_int), ("hidden", C.c_int), ("reserved0", C.c_int)] + [
+        (n, C.c_void_p) for n in ("critic_w0", "critic_b0", "critic_w1", "critic_b1", "critic_w2", "critic_b2", "actor_w0", "actor_b0",
+                                  "actor_w1", "actor_b1", "mean_w", "mean_b", "logstd")]
+
+
+class PpoBatch(C.Structure):                # solorl_ppo_batch
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "old_logp", "adv", "vpred", "ret", "perm", "offset")] + [
+        ("m", C.c_int), ("clipped_value", C.c_int), ("clip", C.c_float), ("value_coef", C.c_float)]
+
+
+class PpoGrads(C.Structure):                # solorl_ppo_grads
+    _fields_ = [(n, C.c_void_p) for n in ("critic_w0", "critic_b0", "critic_w1", "critic_b1", "critic_w2", "critic_b2", "actor_w0", "actor_b0",
+                                          "actor_w1", "actor_b1", "mean_w", "mean_b", "logstd", "loss_sums", "logstd_sum", "scratch")] + [
+        ("entropy_coef", C.c_float), ("reserved0", C.c_float)]
+
+
+class PpoStage1(C.Structure):               # solorl_ppo_stage1
+    _fields_ = [(n, C.c_void_p) for n in ("xt0", "c_xt1", "c_xt2", "c_g1", "c_g2", "c_gh", "a_xt1", "a_xt2", "a_g1", "a_g2", "a_gh", "partials")]
 
 
 class SoloRLError(RuntimeError):
@@ -45,6 +66,10 @@ def lib():
                                       C.c_int, C.c_void_p]
         L.solorl_compute_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                              C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.solorl_policy_act.argtypes = [C.POINTER(PolicyParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.solorl_ppo_grad_stage1.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoBatch), C.POINTER(PpoStage1), C.c_int, C.c_void_p]
+        L.solorl_ppo_grad_stage2.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoStage1), C.c_int, C.POINTER(PpoGrads), C.c_int, C.c_void_p]
+        L.solorl_ppo_grad_count.argtypes = [C.c_int, C.c_int]
         for s in SYMBOLS:
             getattr(L, s)
         _LIB = L

@@ -7,29 +7,48 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("solorl_hip.hip", "dynamics.hpp", "spatial.hpp")]
-DEPS = SRC + [os.path.join(ROOT, "include", f) for f in ("solorl.h", "solorl_model_data.h")]
+INC = [os.path.join(ROOT, "include", f) for f in ("solorl.h", "solorl_model_data.h")]
+# translation units -> what each depends on (the env engine takes ~2.5 min to compile, the PPO kernels seconds: separate objects)
+UNITS = {
+    "solorl_hip.hip": [os.path.join(HERE, "csrc", f) for f in ("solorl_hip.hip", "dynamics.hpp", "spatial.hpp")] + INC,
+    "solorl_ppo.hip": [os.path.join(HERE, "csrc", "solorl_ppo.hip"), INC[0]],
+}
+SRC = UNITS["solorl_hip.hip"][:3]
 LIB = os.path.join(HERE, "_lib", "libsolorl_hip.so")
+OBJ = os.path.join(HERE, "_lib", "obj")
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
 def needs_build():
-    return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+    return any(_stale(LIB, deps) for deps in UNITS.values())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packed fp32 operations appear only where the source writes 2-vectors (the PGS sweep, dynamics.hpp)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
-           "-I" + os.path.join(ROOT, "include"), "-o", LIB + ".tmp", SRC[0]]
-    cmd[1:1] = ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
-    cmd[1:1] = os.environ.get("SOLORL_BUILD_FLAGS", "").split()                                 # dev experiments
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include")]
+    flags += ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
+    flags += os.environ.get("SOLORL_BUILD_FLAGS", "").split()                                 # dev experiments
+    tag = os.path.join(OBJ, "flags.txt")                                                       # objects are only reused for the same flags
+    same = os.path.exists(tag) and open(tag).read() == " ".join(flags)
+    objs = []
+    for name, deps in UNITS.items():
+        o = os.path.join(OBJ, name.replace(".hip", ".o"))
+        if force or not same or _stale(o, deps):
+            cmd = [hipcc] + flags + ["-c", "-o", o, deps[0]]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    open(tag, "w").write(" ".join(flags))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

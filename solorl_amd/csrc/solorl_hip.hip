@@ -1077,6 +1077,8 @@ int check_cfg(const solorl_config* c) {
 extern "C" {
 
 const char* solorl_last_error(void) { return g_err.c_str(); }
+// (the library's other translation units report through the same thread-local message; not part of the ABI)
+extern "C" __attribute__((visibility("hidden"))) int solorl_fail_(int code, const char* msg) { return fail(code, msg); }
 
 #ifdef SOLO_WAVE_TIMING
 extern "C" int solorl_debug_wave_times(unsigned long long* out, int nwaves, int reset) {    // [nwaves][SOLO_WT_FIELDS]

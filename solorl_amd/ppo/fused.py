@@ -48,3 +48,125 @@ class _FusedPPOLoss(torch.autograd.Function):
 def fused_ppo_loss(mean, logstd, values, action, old_logp, adv, vpred, ret, clip, value_coef, entropy_coef, clipped_value=True):
     """-> (loss, value_loss, action_loss, entropy); loss = value_loss*value_coef + action_loss - entropy*entropy_coef."""
     return _FusedPPOLoss.apply(mean, logstd, values, action, old_logp, adv, vpred, ret, clip, value_coef, entropy_coef, clipped_value)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hand-written policy kernels (csrc/solorl_ppo.hip): the whole forward of Policy.act in one launch, and one PPO mini-batch's
+# gather + forward + losses + back-propagation in one launch (the weight gradients stay GEMMs).
+
+_SUPPORTED = {(76, 12), (84, 12), (60, 8), (68, 8)}
+
+
+def policy_kernels_supported(actor_critic):
+    """The kernels are built for the reference's default MLP (hidden 64, agents/ppo/policy.py:62-81) on one history level."""
+    b = actor_critic.base
+    try:
+        o, h, a = b.features[0].in_features, b.features[0].out_features, actor_critic.pi_dist.mean.out_features
+    except AttributeError:
+        return False
+    p = next(actor_critic.parameters())
+    return h == 64 and (o, a) in _SUPPORTED and p.is_cuda and p.dtype == torch.float32
+
+
+def policy_params(actor_critic):
+    """solorl_policy_params over the module's own parameter storage (PyTorch layout is the kernels' layout: no copies).
+    The pointers stay valid as long as the parameters are updated in place (optimizers do)."""
+    b, d = actor_critic.base, actor_critic.pi_dist
+    P = _native.PolicyParams()
+    P.obs_dim, P.hidden, P.act_dim = b.features[0].in_features, b.features[0].out_features, d.mean.out_features
+    named = {"critic_w0": b.critic[0].weight, "critic_b0": b.critic[0].bias, "critic_w1": b.critic[2].weight, "critic_b1": b.critic[2].bias,
+             "critic_w2": b.critic[4].weight, "critic_b2": b.critic[4].bias, "actor_w0": b.features[0].weight, "actor_b0": b.features[0].bias,
+             "actor_w1": b.features[2].weight, "actor_b1": b.features[2].bias, "mean_w": d.mean.weight, "mean_b": d.mean.bias,
+             "logstd": d.logstd}
+    for k, t in named.items():
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+        setattr(P, k, t.data_ptr())
+    return P
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def policy_act(params, obs, noise, value_out, action_out, logp_out):
+    """Policy.act (agents/ppo/policy.py:33-49) in one launch: value_out [N,1], action_out [N,A] = mean + exp(logstd) * noise
+    (noise [N,A] standard normal, or None for the deterministic action), logp_out [N,1]."""
+    n = obs.shape[0]
+    dev = obs.device
+    for t in (obs, value_out, action_out, logp_out) + (() if noise is None else (noise,)):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert obs.shape == (n, params.obs_dim) and action_out.shape == (n, params.act_dim) and value_out.numel() == n and logp_out.numel() == n
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().solorl_policy_act(C.byref(params), C.c_void_p(obs.data_ptr()),
+                                                      C.c_void_p(0 if noise is None else noise.data_ptr()), n, C.c_void_p(value_out.data_ptr()),
+                                                      C.c_void_p(action_out.data_ptr()), C.c_void_p(logp_out.data_ptr()), dev.index or 0, _stream(dev)))
+
+
+class MiniBatchGrad:
+    """One PPO mini-batch step's gradients without autograd, three launches: solorl_ppo_grad_stage1 (gather, forward, losses,
+    back-propagation to every layer's pre-activation gradient, [unit][row] layout), then solorl_ppo_grad_stage2 (the weight
+    gradients G^T X of the six layers over row chunks, and their fixed-order sum written straight into the parameters' .grad --
+    views of the flat bucket -- with the log-std gradient and the running loss sums).  Same arithmetic as PPO.update's
+    loss.backward() (agents/ppo/ppo.py:46-74) in a different summation order."""
+    SLICE = 64                        # mini-batch rows must fill whole wavefronts
+
+    def __init__(self, actor_critic, storage, mini_batch, clip, value_coef, entropy_coef, clipped_value, perm, offset, adv):
+        n, m = storage.num_samples, mini_batch
+        assert m % self.SLICE == 0, "mini-batch must be a multiple of %d rows" % self.SLICE
+        dev = storage.device
+        self.ac, self.m = actor_critic, m
+        self.P = policy_params(actor_critic)
+        O, A, H = self.P.obs_dim, self.P.act_dim, 64
+        self.A = A
+        flat = lambda x: x.reshape(n, *x.shape[2:])
+        B = self.B = _native.PpoBatch()
+        self._keep = (flat(storage.obs[:-1]), flat(storage.actions), flat(storage.action_log_probs), adv, flat(storage.value_preds[:-1]),
+                      flat(storage.returns[:-1]), perm, offset)
+        for k, t in zip(("obs", "actions", "old_logp", "adv", "vpred", "ret", "perm", "offset"), self._keep):
+            assert t.is_contiguous() and t.is_cuda
+            setattr(B, k, t.data_ptr())
+        assert self._keep[0].data_ptr() == storage.obs.data_ptr() and perm.dtype == torch.long and offset.dtype == torch.long
+        B.m, B.clipped_value, B.clip, B.value_coef = m, int(bool(clipped_value)), float(clip), float(value_coef)
+
+        def xt(units):                       # [units + 1][m]: the last row stays 1 -> the bias gradient is the product's last column
+            t = torch.zeros(units + 1, m, device=dev)
+            t[units].fill_(1.0)
+            return t
+        z = lambda u: torch.zeros(u, m, device=dev)
+        self.buf = dict(xt0=xt(O), c_xt1=xt(H), c_xt2=xt(H), c_g1=z(H), c_g2=z(H), c_gh=z(1), a_xt1=xt(H), a_xt2=xt(H), a_g1=z(H), a_g2=z(H),
+                        a_gh=z(A), partials=torch.zeros((m + 63) // 64, 3 + A, device=dev))
+        W = self.W = _native.PpoStage1()
+        for k, t in self.buf.items():
+            setattr(W, k, t.data_ptr())
+        b, d = actor_critic.base, actor_critic.pi_dist
+        self.psum = torch.zeros(3 + A, device=dev)          # running sums of the partials over the steps of an update
+        self.ent = torch.zeros(1, device=dev)               # running sum of sum_a logstd_a
+        L = _native.lib()
+        self.scratch = torch.zeros(((m + 4095) // 4096) * L.solorl_ppo_grad_count(O, A), device=dev)
+        G = self.G = _native.PpoGrads()
+        grads = {"critic_w0": b.critic[0].weight, "critic_b0": b.critic[0].bias, "critic_w1": b.critic[2].weight, "critic_b1": b.critic[2].bias,
+                 "critic_w2": b.critic[4].weight, "critic_b2": b.critic[4].bias, "actor_w0": b.features[0].weight, "actor_b0": b.features[0].bias,
+                 "actor_w1": b.features[2].weight, "actor_b1": b.features[2].bias, "mean_w": d.mean.weight, "mean_b": d.mean.bias,
+                 "logstd": d.logstd}
+        for k, prm in grads.items():
+            g = prm.grad
+            assert g is not None and g.is_contiguous() and g.shape == prm.shape, "parameters need dense .grad tensors (FlatGradBucket)"
+            setattr(G, k, g.data_ptr())
+        G.loss_sums, G.logstd_sum, G.scratch, G.entropy_coef = self.psum.data_ptr(), self.ent.data_ptr(), self.scratch.data_ptr(), float(entropy_coef)
+
+    def __call__(self):
+        dev = self.psum.device
+        L = _native.lib()
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            _native.check(L.solorl_ppo_grad_stage1(C.byref(self.P), C.byref(self.B), C.byref(self.W), dev.index or 0, st))
+            _native.check(L.solorl_ppo_grad_stage2(C.byref(self.P), C.byref(self.W), self.m, C.byref(self.G), dev.index or 0, st))
+
+    def losses(self, steps):
+        """(value loss, action loss, entropy) averaged over `steps` mini-batch steps since reset()."""
+        v, a = (self.psum[:2] / (self.m * max(steps, 1))).tolist()
+        e = 0.5 + _HALF_LOG_2PI + self.ent.item() / (self.A * max(steps, 1))
+        return v, a, e
+
+    def reset(self):
+        self.psum.zero_(); self.ent.zero_()

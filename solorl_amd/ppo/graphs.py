@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as D
-from .fused import fused_ppo_loss
+from .fused import MiniBatchGrad, fused_ppo_loss, policy_act, policy_kernels_supported, policy_params
 from .ppo import PPO
 
 
@@ -53,8 +53,14 @@ class GraphedRollout:
         # observations / rewards go straight into the storage rows (the C ABI takes caller-owned pointers), masks = 1 - done in
         # one launch -- 19 launches per step instead of 35, and launches are what a step costs besides the env kernel
         one = torch.ones((), device=st.device)
+        fused = policy_kernels_supported(self.ac)
+        if fused:                            # one launch for the whole of Policy.act (csrc/solorl_ppo.hip) + one for the noise
+            self._pp = policy_params(self.ac)
         for t in range(self.T):
-            self.ac.act_into(st.obs[t], st.value_preds[t], st.actions[t], st.action_log_probs[t])
+            if fused:
+                policy_act(self._pp, st.obs[t], torch.randn_like(st.actions[t]), st.value_preds[t], st.actions[t], st.action_log_probs[t])
+            else:
+                self.ac.act_into(st.obs[t], st.value_preds[t], st.actions[t], st.action_log_probs[t])
             _, _, done, _ = self.envs.step_inplace(st.actions[t], obs_out=st.obs[t + 1], rew_out=st.rewards[t])
             torch.sub(one, done, out=st.masks[t + 1].view(-1))
 
@@ -85,10 +91,12 @@ class GraphedPPO(PPO):
     device tensor (update_linear_schedule fills it), otherwise the arithmetic is PPO.update's."""
 
     def __init__(self, actor_critic, clip_param, ppo_epoch, mini_batch_size, value_loss_coef, entropy_coef, lr=None,
-                 l2_coef=0.0, max_grad_norm=None, use_clipped_value_loss=True, fused_loss=True):
+                 l2_coef=0.0, max_grad_norm=None, use_clipped_value_loss=True, fused_loss=True, fused_mlp=True):
         super().__init__(actor_critic, clip_param, ppo_epoch, mini_batch_size, value_loss_coef, entropy_coef, lr=lr,
                          l2_coef=l2_coef, max_grad_norm=max_grad_norm, use_clipped_value_loss=use_clipped_value_loss)
         self.fused_loss = fused_loss
+        # hand-written mini-batch kernel (csrc/solorl_ppo.hip) where it is built for this policy's shape; otherwise autograd
+        self.fused_mlp = fused_mlp and policy_kernels_supported(actor_critic)
         dev = next(actor_critic.parameters()).device
         # (fused: one multi-tensor launch per optimizer step instead of a dozen -- a captured mini-batch step is ~100 launches of a
         # few microseconds each, so launches are what it costs)
@@ -111,8 +119,16 @@ class GraphedPPO(PPO):
         self._ar = torch.arange(m, device=dev)
         self._stats = torch.zeros(3, device=dev)
         clip = self.clip_param
+        self._mb = None
+        if self.fused_mlp and m % MiniBatchGrad.SLICE == 0:
+            self._mb = MiniBatchGrad(self.actor_critic, storage, m, clip, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss,
+                                     self._perm, self._off, self._adv)
 
         def fwd_bwd():
+            if self._mb is not None:     # three launches: gather + forward + losses + back-propagation; weight gradients; their sum
+                self._mb()
+                self._off += m
+                return
             idx = self._perm.index_select(0, self._ar + self._off)
             self._off += m
             obs_b, act_b, vpred_b, ret_b, old_lp_b = (s.index_select(0, idx) for s in self._src)
@@ -161,6 +177,8 @@ class GraphedPPO(PPO):
                     if torch.is_tensor(v):
                         v.zero_()
         self._stats.zero_(); self._off.zero_()
+        if self._mb is not None:
+            self._mb.reset()
         self._split = D.world() > 1
         pool = torch.cuda.graph_pool_handle()
         self._g1 = torch.cuda.CUDAGraph()
@@ -186,6 +204,8 @@ class GraphedPPO(PPO):
         mean, std = D.global_mean_std(adv, unbiased=True)
         self._adv.copy_(((adv - mean) / (std + 1e-5)).reshape(n, 1))
         self._stats.zero_()
+        if self._mb is not None:
+            self._mb.reset()
         n_updates = 0
         for _ in range(self.ppo_epoch):
             self._perm.copy_(torch.randperm(n, device=storage.device))
@@ -196,5 +216,7 @@ class GraphedPPO(PPO):
                     self.bucket.all_reduce_mean()
                     self._g2.replay()
                 n_updates += 1
+        if self._mb is not None:
+            return self._mb.losses(n_updates)
         v, a, e = (self._stats / max(n_updates, 1)).tolist()
         return v, a, e

@@ -21,7 +21,7 @@ def lib():
 
 def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "solorl.h")).read()
-    declared = set(re.findall(r"\b(solorl_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(solorl_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_native.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)

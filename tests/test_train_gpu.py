@@ -212,3 +212,114 @@ def test_graphed_rollout_fills_the_storage_like_the_eager_loop(gpu_device):
         assert torch.equal(o, g["obs"][t + 1]) and torch.equal(r.view(-1), g["rewards"][t].view(-1))
         assert torch.equal(1.0 - d.float(), g["masks"][t + 1].view(-1))
     env.close()
+
+
+def _random_policy(dev, O=76, A=12, seed=0):
+    import numpy as np
+    from solorl_amd.ppo import Policy
+    from solorl_amd.vec_env import Box
+    torch.manual_seed(seed)
+    pol = Policy((O,), Box(-np.ones(A), np.ones(A)), None, {"hidden_size": 64}).to(dev)
+    with torch.no_grad():
+        pol.pi_dist.logstd.normal_(0, 0.3)
+        for p in pol.parameters():
+            if p.dim() == 1 and p is not pol.pi_dist.logstd:
+                p.normal_(0, 0.1)                   # non-zero biases
+    return pol
+
+
+@pytest.mark.parametrize("O,A", [(76, 12), (84, 12), (60, 8), (68, 8)])
+def test_policy_act_kernel_matches_torch(gpu_device, O, A):
+    """solorl_policy_act (one launch) == Policy.act_into (agents/ppo/policy.py:33-49 arithmetic in torch), ragged row count,
+    with noise and deterministic."""
+    from solorl_amd.ppo.fused import policy_act, policy_params, policy_kernels_supported
+    dev = torch.device("cuda:0")
+    pol = _random_policy(dev, O, A)
+    assert policy_kernels_supported(pol)
+    P = policy_params(pol)
+    n = 1000
+    obs = torch.randn(n, O, device=dev)
+    for noise in (torch.randn(n, A, device=dev), None):
+        v0, a0, l0 = torch.empty(n, 1, device=dev), torch.empty(n, A, device=dev), torch.empty(n, 1, device=dev)
+        pol.act_into(obs, v0, a0, l0, noise=noise if noise is not None else torch.zeros(n, A, device=dev))
+        v1, a1, l1 = torch.full((n, 1), 7.0, device=dev), torch.full((n, A), 7.0, device=dev), torch.full((n, 1), 7.0, device=dev)
+        policy_act(P, obs, noise, v1, a1, l1)
+        assert torch.allclose(v0, v1, rtol=1e-4, atol=1e-5), (v0 - v1).abs().max().item()
+        assert torch.allclose(a0, a1, rtol=1e-4, atol=1e-5), (a0 - a1).abs().max().item()
+        assert torch.allclose(l0, l1, rtol=1e-4, atol=1e-4), (l0 - l1).abs().max().item()
+
+
+@pytest.mark.parametrize("O,A,clipped", [(76, 12, True), (84, 12, False), (60, 8, True)])
+def test_minibatch_grad_kernel_matches_autograd(gpu_device, O, A, clipped):
+    """MiniBatchGrad (solorl_ppo_grad_stage1 + row-sliced GEMMs) against loss.backward() of the reference's formulas
+    (agents/ppo/ppo.py:46-74) on the same mini-batch: every parameter's gradient, and the three loss values."""
+    from solorl_amd.ppo import RolloutStorage
+    from solorl_amd.ppo import dist as D
+    from solorl_amd.ppo.fused import MiniBatchGrad
+    dev = torch.device("cuda:0")
+    T, N, m, clip, vc, ec = 16, 128, 1024, 0.1, 0.5, 0.01
+    pol = _random_policy(dev, O, A, seed=1)
+    st = RolloutStorage(T, N, (O,), A, dev)
+    torch.manual_seed(2)
+    st.obs.normal_(); st.actions.normal_(); st.value_preds.normal_(); st.returns.normal_()
+    n = T * N
+    flat = lambda x: x.reshape(n, *x.shape[2:])
+    with torch.no_grad():                      # old log-probs near the current ones, so that ratios straddle the clip interval
+        _, lp, _ = pol.evaluate_actions(flat(st.obs[:-1]), flat(st.actions))
+        st.action_log_probs.copy_((lp + 0.15 * torch.randn_like(lp)).view(T, N, 1))
+    adv = torch.randn(n, 1, device=dev)
+    perm = torch.randperm(n, device=dev)
+    off = torch.full((), 512, dtype=torch.long, device=dev)
+    bucket = D.FlatGradBucket(pol.parameters())
+    mb = MiniBatchGrad(pol, st, m, clip, vc, ec, clipped, perm, off, adv)
+    bucket.flat.fill_(123.0)                    # every gradient element must be overwritten
+    mb()
+    g_kernel = bucket.flat.clone()
+    vl_k, al_k, ent_k = mb.losses(1)
+    # autograd reference on the same rows
+    idx = perm[512:512 + m]
+    obs_b, act_b = flat(st.obs[:-1])[idx], flat(st.actions)[idx]
+    vpred_b, ret_b, old_b, adv_b = flat(st.value_preds[:-1])[idx], flat(st.returns[:-1])[idx], flat(st.action_log_probs)[idx], adv[idx]
+    values, logp, entropy = pol.evaluate_actions(obs_b, act_b)
+    ratio = torch.exp(logp - old_b)
+    al = -torch.min(ratio * adv_b, torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * adv_b).mean()
+    if clipped:
+        v_clipped = vpred_b + (values - vpred_b).clamp(-clip, clip)
+        vl = 0.5 * torch.max((values - ret_b).pow(2), (v_clipped - ret_b).pow(2)).mean()
+    else:
+        vl = 0.5 * (ret_b - values).pow(2).mean()
+    bucket.zero()
+    (vl * vc + al - entropy * ec).backward()
+    g_ref = bucket.flat
+    assert (ratio < 1 - clip).any() and (ratio > 1 + clip).any()
+    scale = g_ref.abs().max().item()
+    assert torch.allclose(g_kernel, g_ref, rtol=2e-3, atol=2e-5 * scale), ((g_kernel - g_ref).abs().max().item(), scale)
+    assert abs(vl_k - vl.item()) < 1e-4 * max(1.0, abs(vl.item())) and abs(al_k - al.item()) < 1e-5 + 1e-4 * abs(al.item())
+    assert abs(ent_k - entropy.item()) < 1e-5
+
+
+def test_hip_graph_update_with_the_minibatch_kernel_matches_eager(gpu_device):
+    """GraphedPPO on its hand-written mini-batch path (mini-batch a multiple of 512 rows) == PPO.update, as the autograd graph path above."""
+    import copy
+    import numpy as np
+    from solorl_amd.ppo import PPO, RolloutStorage
+    from solorl_amd.ppo.graphs import GraphedPPO
+    dev = torch.device("cuda:0")
+    T, N, O, A = 16, 128, 76, 12
+    torch.manual_seed(0)
+    st = RolloutStorage(T, N, (O,), A, dev)
+    st.obs.normal_(); st.actions.normal_(); st.rewards.normal_(); st.value_preds.normal_(); st.action_log_probs.normal_().mul_(0.1).sub_(10)
+    st.masks.copy_((torch.rand_like(st.masks) > 0.05).float())
+    st.compute_returns(torch.randn(N, 1, device=dev), True, 0.99, 0.95)
+    pol_a = _random_policy(dev, O, A, seed=4)
+    pol_b = copy.deepcopy(pol_a)
+    eager = PPO(pol_a, 0.1, 2, 512, 0.5, 0.01, lr=1e-3, max_grad_norm=0.5)
+    graph = GraphedPPO(pol_b, 0.1, 2, 512, 0.5, 0.01, lr=1e-3, max_grad_norm=0.5)
+    for it in range(2):
+        torch.manual_seed(5 + it); la = eager.update(st)
+        torch.manual_seed(5 + it); lb = graph.update(st)
+        assert graph._mb is not None
+        assert np.allclose(la, lb, rtol=1e-4, atol=1e-5), (la, lb)
+        va = torch.cat([p.detach().flatten() for p in pol_a.parameters()])
+        vb = torch.cat([p.detach().flatten() for p in pol_b.parameters()])
+        assert ((va - vb).norm() / va.norm()).item() < 1e-3 and (va - vb).abs().max().item() < 5e-3
