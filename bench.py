@@ -162,7 +162,7 @@ def ppo_leg(env, dev, world, T, epochs):
         t_roll, t_all = tt.tolist()
     out = {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
            "ppo_epoch": epochs, "mini_batches_per_epoch": 50, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
-           "note": "policy forward + env.step + storage per step, then GAE + PPO epochs; rollout and mini-batch step replayed from HIP graphs"}
+           "note": "policy act (solorl_policy_act) + env.step writing into the rollout storage per step, then GAE + PPO epochs (solorl_ppo_grad_stage1/2 + clip + Adam per mini-batch); rollout and mini-batch step replayed from HIP graphs"}
     if world > 1:                   # the collective of the data-parallel PPO step, timed on its own
         reps = 50
         sync(); t0 = time.perf_counter()

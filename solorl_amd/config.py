@@ -127,7 +127,8 @@ def config_from_dict(d, **overrides):
     if control not in CONTROLS:
         raise NotImplementedError("control %r (reference solo.py:253-254)" % (control,))
     if not d.get("flat_ground", True):
-        raise NotImplementedError("heightfield terrain (simulation.py:79-154) is out of scope")
+        raise NotImplementedError("heightfield terrain (simulation.py:79-154) is out of scope (the reference itself fails to load it: "
+                                  "simulation.py:28 calls Heightfield() without the required stepwidth)")
     c = default_config(robot, TASKS[task])
     c.control = CONTROLS[control]
     c.frame_skip = int(d.get("frame_skip", 4))
