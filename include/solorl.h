@@ -231,7 +231,7 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
  *   loss_sums [3 + A]  += (sum value loss, sum action loss, rows, sum d action-loss / d logstd) of this mini-batch,
  *   logstd_sum [1]     += sum_a logstd_a            (entropy = 0.5 + log sqrt(2 pi) + mean_a logstd_a, policy.py:56)
  *   logstd             = sum d action-loss / d logstd - entropy_coef / A       (the complete gradient of ppo.py:74's loss)
- *   scratch            >= ceil(m / 4096) * solorl_ppo_grad_count(obs_dim, act_dim) floats of working memory.
+ *   scratch            >= ceil(m / 512) * solorl_ppo_grad_count(obs_dim, act_dim) floats of working memory.
  * Sums are taken in a fixed order: results are reproducible run to run. */
 typedef struct solorl_ppo_grads {
   float *critic_w0, *critic_b0, *critic_w1, *critic_b1, *critic_w2, *critic_b2;

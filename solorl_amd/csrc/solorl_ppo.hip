@@ -5,18 +5,15 @@
 // microseconds of work each; replayed from a HIP graph they still cost ~5 us apiece, which made the rollout 0.27 ms per
 // step around a 0.17 ms env kernel and a mini-batch step 0.5 ms around ~50 us of arithmetic (profiles/r02_notes.md).
 //
-//   policy_act_kernel        value, sampled action and its log-prob for N observation rows          (policy.py:33-49 act)
-//   ppo_grad_stage1_kernel   one mini-batch: gather, both MLPs forward, the clipped PPO losses (ppo.py:52-74) and the
-//                            back-propagated pre-activation gradients of every layer, written [unit][row] so that the
-//                            weight gradients are plain (row-sliced) GEMMs G^T X for the caller
+//   policy_act_mfma_kernel       value, sampled action and its log-prob for N observation rows      (policy.py:33-49 act)
+//   ppo_grad_stage1_mfma_kernel  one mini-batch: gather, both MLPs forward, the clipped PPO losses (ppo.py:52-74) and the
+//                                back-propagated pre-activation gradients of every layer, written [unit][row]
+//   ppo_grad_stage2_mfma_kernel  the weight gradients G X^T of the six layers over row chunks
+//   ppo_grad_stage3_kernel       their fixed-order sum into the parameters' gradients, log-std gradient, loss bookkeeping
 //
-// Mapping: one lane = one row (sample).  The weights are then wave-uniform.  A first version fetched them with scalar loads
-// (every multiply-add a single v_fma with an SGPR operand) and was latency-bound on exactly those loads: ~100 SGPRs hold one
-// 16-dword chunk per accumulator plus one in flight, 1024 wavefronts stream 39 KB of weights each through the small scalar
-// cache, and a mini-batch took 141 us (21 cycles per multiply-add).  Now a workgroup stages its net's weights in LDS once
-// (39 KB) and every lane reads them back as broadcast ds_read_b128 -- four weights per read, no bank conflicts, VGPR operands
-// the compiler can prefetch as deep as it likes.  A layer is a run-time loop over output units (four at a time: independent
-// accumulation chains) with the input vector in registers.
+// The three product kernels run on the matrix cores (exact-f32 MFMA), see "MFMA formulation" below.  Two VALU formulations
+// (lane = row; weights through scalar loads, then through LDS broadcast reads) were built and measured first:
+// profiles/r02_notes.md.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -39,380 +36,17 @@ constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 #define CRITIC_PASS P.critic_w0, P.critic_b0, P.critic_w1, P.critic_b1, P.critic_w2, P.critic_b2
 #define ACTOR_PASS P.actor_w0, P.actor_b0, P.actor_w1, P.actor_b1, P.mean_w, P.mean_b, P.logstd
 
-// one net's parameters in LDS, PyTorch layout ([out][in] row-major), every block 16-byte aligned
-template <int O, int NOUT> struct NetLds {
-  static constexpr int NHP = (NOUT + 3) & ~3;
-  static constexpr int W0 = 0, W1 = W0 + H * O, WH = W1 + H * H, B0 = WH + NHP * H, B1 = B0 + H, BH = B1 + H, FLOATS = BH + NHP;
-  float* p;
-  __device__ __forceinline__ const float* w0() const { return p + W0; }
-  __device__ __forceinline__ const float* w1() const { return p + W1; }
-  __device__ __forceinline__ const float* wh() const { return p + WH; }
-  __device__ __forceinline__ const float* b0() const { return p + B0; }
-  __device__ __forceinline__ const float* b1() const { return p + B1; }
-  __device__ __forceinline__ const float* bh() const { return p + BH; }
-  // cooperative copy by the whole workgroup; the caller synchronises
-  __device__ __forceinline__ void stage(NET_ARGS) const {
-    auto copy = [&](float* dst, const float* __restrict__ src, int n) {
-      for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    };
-    copy(p + W0, w0, H * O); copy(p + W1, w1, H * H); copy(p + WH, wh, NOUT * H);
-    copy(p + B0, b0, H); copy(p + B1, b1, H); copy(p + BH, bh, NOUT);
-  }
-};
-
-__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// Order fence for the software-pipelined loops below: the accumulators pass through an empty volatile asm with a memory
-// clobber, so the multiply-adds of the group before it cannot sink below it and the reads after it cannot rise above it.
-// (A scheduling-barrier builtin alone does not do this: it pins memory operations, but instruction selection is free to place
-// the arithmetic anywhere, and it put every read of a layer ahead of the first multiply-add -- 1.1 KB of spills per lane.)
-template <int N> __device__ __forceinline__ void fence(float (&a)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]) : : "memory");
-}
-
-// out[j] = act(b[j] + sum_i w[j * NIN + i] * in[i]),  j0 <= j < j1 (a multiple of four outputs), w and b in LDS.
-// The input loop is fully unrolled (the input vector is a register array); left alone the scheduler hoists all 4 x NIN / 4
-// broadcast reads of an iteration to its top and spills, so the reads go in groups of 8 inputs x 4 outputs (32 VGPRs) separated
-// by scheduling barriers, two groups ahead of the multiply-adds that consume them.
-template <int NIN, bool TANH, typename Store>
-__device__ __forceinline__ void dense(const float (&in)[NIN], const float* w, const float* b, int j0, int j1, Store&& store) {
-  static_assert(NIN % 4 == 0, "input width in float4");
-  constexpr int NQ = NIN / 4, GQ = 2, NG = (NQ + GQ - 1) / GQ, LA = 2;     // float4 per row, per group; groups; lookahead
-#pragma unroll 1
-  for (int j = j0; j < j1; j += 4) {
-    const float* wj = w + j * NIN;
-    const float4 bv = lds4(b + j);
-    float acc[4] = {bv.x, bv.y, bv.z, bv.w};
-    float4 wb[NQ][4];
-    auto fetch = [&](int g) {
-#pragma unroll
-      for (int q = g * GQ; q < (g + 1) * GQ && q < NQ; ++q)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) wb[q][o] = lds4(wj + o * NIN + 4 * q);
-    };
-#pragma unroll
-    for (int g = 0; g < LA && g < NG; ++g) fetch(g);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + LA < NG) fetch(g + LA);
-#pragma unroll
-      for (int q = g * GQ; q < (g + 1) * GQ && q < NQ; ++q)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          acc[o] = fmaf(wb[q][o].x, in[4 * q], acc[o]); acc[o] = fmaf(wb[q][o].y, in[4 * q + 1], acc[o]);
-          acc[o] = fmaf(wb[q][o].z, in[4 * q + 2], acc[o]); acc[o] = fmaf(wb[q][o].w, in[4 * q + 3], acc[o]);
-        }
-      fence(acc);
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) store(j + o, TANH ? tanhf(acc[o]) : acc[o]);
-  }
-}
-
-// the same for a head of NOUT outputs, fully unrolled so that out[] is a register array; one output's 16 reads per group
-template <int NOUT> __device__ __forceinline__ void dense_head(const float (&in)[H], const float* w, const float* b, float (&out)[NOUT]) {
-  float4 wb[NOUT][H / 4];
-  auto fetch = [&](int j) {
-#pragma unroll
-    for (int q = 0; q < H / 4; ++q) wb[j][q] = lds4(w + j * H + 4 * q);
-  };
-  fetch(0);
-#pragma unroll
-  for (int j = 0; j < NOUT; ++j) {
-    if (j + 1 < NOUT) fetch(j + 1);
-    float a[2] = {b[j], 0.f};
-#pragma unroll
-    for (int q = 0; q < H / 4; ++q) {
-      a[0] = fmaf(wb[j][q].x, in[4 * q], a[0]); a[1] = fmaf(wb[j][q].y, in[4 * q + 1], a[1]);
-      a[0] = fmaf(wb[j][q].z, in[4 * q + 2], a[0]); a[1] = fmaf(wb[j][q].w, in[4 * q + 3], a[1]);
-    }
-    fence(a);
-    out[j] = a[0] + a[1];
-  }
-}
-
-// out[k] = sum_j w[j * H + k] * g[j],  k < H     (back-propagation through a layer with H inputs and NJ outputs), w in LDS;
-// eight k at a time, reads grouped (4 j x 8 k = 32 VGPRs) and issued two groups ahead as in dense()
-template <int NJ, typename Store>
-__device__ __forceinline__ void dense_t(const float (&g)[NJ], const float* w, Store&& store) {
-  constexpr int KC = 8, GJ = NJ >= 4 ? 4 : NJ, NG = (NJ + GJ - 1) / GJ, LA = 2;
-#pragma unroll 1
-  for (int k = 0; k < H; k += KC) {
-    float acc[KC];
-#pragma unroll
-    for (int o = 0; o < KC; ++o) acc[o] = 0.f;
-    float4 wb[NJ][KC / 4];
-    auto fetch = [&](int gi) {
-#pragma unroll
-      for (int j = gi * GJ; j < (gi + 1) * GJ && j < NJ; ++j)
-#pragma unroll
-        for (int q = 0; q < KC / 4; ++q) wb[j][q] = lds4(w + j * H + k + 4 * q);
-    };
-#pragma unroll
-    for (int gi = 0; gi < LA && gi < NG; ++gi) fetch(gi);
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-      if (gi + LA < NG) fetch(gi + LA);
-#pragma unroll
-      for (int j = gi * GJ; j < (gi + 1) * GJ && j < NJ; ++j)
-#pragma unroll
-        for (int q = 0; q < KC / 4; ++q) {
-          acc[4 * q] = fmaf(wb[j][q].x, g[j], acc[4 * q]); acc[4 * q + 1] = fmaf(wb[j][q].y, g[j], acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(wb[j][q].z, g[j], acc[4 * q + 2]); acc[4 * q + 3] = fmaf(wb[j][q].w, g[j], acc[4 * q + 3]);
-        }
-      fence(acc);
-    }
-#pragma unroll
-    for (int o = 0; o < KC; ++o) store(k + o, acc[o]);
-  }
-}
-
-template <int O> __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[O]) {
-  static_assert(O % 4 == 0, "observation rows are read as float4");
-#pragma unroll
-  for (int i = 0; i < O; i += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(p + i);
-    x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
-  }
-}
-
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
   return x;
 }
 
-// ------------------------------------------------------------------------------------------------ act
-// grid (ceil(n / 64), 2): blockIdx.y = 0 critic (value), 1 actor (action, log-prob).  256 threads = four wavefronts working on
-// the SAME 64 rows: each computes a quarter of a layer's units and they meet in LDS ([unit][row]) -- at 4096 envs the rollout
-// waits for this kernel, so its latency counts, not its throughput.
-template <int O, int A, bool ACTOR>
-__device__ __forceinline__ void act_net(NET_ARGS, const float* __restrict__ logstd, const float* __restrict__ obs,
-                                        const float* __restrict__ noise, int n, float* value_out, float* action_out, float* logp_out,
-                                        float* smem) {
-  constexpr int NOUT = ACTOR ? A : 1;
-  using NL = NetLds<O, NOUT>;
-  const NL net{smem};
-  float* hb = smem + ((NL::FLOATS + 3) & ~3);            // [H][64]
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 64 + lane;
-  const bool on = row < n;
-  const int r = on ? row : n - 1;
-  net.stage(w0, b0, w1, b1, wh, bh);
-  float x[O];
-  load_row<O>(obs + (size_t)r * O, x);
-  __syncthreads();
-  auto to_lds = [&](int j, float v) { hb[j * 64 + lane] = v; };
-  float h[H];
-  dense<O, true>(x, net.w0(), net.b0(), 16 * wv, 16 * wv + 16, to_lds);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < H; ++j) h[j] = hb[j * 64 + lane];
-  __syncthreads();
-  dense<H, true>(h, net.w1(), net.b1(), 16 * wv, 16 * wv + 16, to_lds);
-  __syncthreads();
-  if (wv != 0) return;                                   // the heads are small: one wavefront finishes
-#pragma unroll
-  for (int j = 0; j < H; ++j) h[j] = hb[j * 64 + lane];
-  float out[NOUT];
-  dense_head<NOUT>(h, net.wh(), net.bh(), out);
-  if constexpr (!ACTOR) {
-    if (on) value_out[row] = out[0];
-  } else {
-    float lp = 0.f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      const float mean = out[a], ls = logstd[a];
-      const float act = noise ? fmaf(expf(ls), noise[(size_t)r * A + a], mean) : mean;       // policy.py:40-43
-      const float z = (act - mean) * expf(-ls);                                              // ModNormal.log_probs, policy.py:171-173
-      lp += -0.5f * z * z - ls - HALF_LOG_2PI;
-      if (on) action_out[(size_t)row * A + a] = act;
-    }
-    if (on) logp_out[row] = lp;
-  }
-}
-
-template <int O, int A> constexpr size_t act_smem_bytes() { return (size_t)(((NetLds<O, A>::FLOATS + 3) & ~3) + H * 64) * sizeof(float); }
-
-template <int O, int A>
-__global__ void __launch_bounds__(256)
-policy_act_kernel(CRITIC_ARGS, ACTOR_ARGS, const float* __restrict__ obs, const float* __restrict__ noise, int n, float* value_out,
-                  float* action_out, float* logp_out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (blockIdx.y == 0) act_net<O, A, false>(cw0, cb0, cw1, cb1, cwh, cbh, nullptr, obs, noise, n, value_out, action_out, logp_out, smem);
-  else act_net<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, obs, noise, n, value_out, action_out, logp_out, smem);
-}
-
-// ------------------------------------------------------------------------------------------------ mini-batch gradients, stage 1
-// grid (ceil(m / 256), 2): blockIdx.y = 0 critic, 1 actor; 256 threads = 256 rows sharing one LDS copy of the net.
-// Row r of the mini-batch is sample perm[*offset + r].
-// Outputs, all [unit][m] (coalesced for lane = row; the caller's GEMMs read them as K-major operands):
-//   xt0 [O][m]        gathered observations                         (written by the critic blocks)
-//   xt1, xt2 [H][m]   hidden activations of the net
-//   g1, g2 [H][m]     d loss / d pre-activation of hidden layer 1, 2
-//   gh [NOUT][m]      d loss / d head output (critic: value_coef * d value-loss / d v; actor: d action-loss / d mean)
-//   partials [ceil(m/64)][3 + A] per wavefront: critic [0] = sum value loss; actor [1] = sum action loss, [2] = rows,
-//                             [3 + a] = sum d action-loss / d logstd_a          (the caller adds them and the entropy term)
-// Loss arithmetic and sub-gradient conventions: ppo_loss_kernel in solorl_hip.hip (agents/ppo/ppo.py:52-74).
-template <int O, int A, bool ACTOR>
-__device__ __forceinline__ void grad_net(NET_ARGS, const float* __restrict__ logstd, const solorl_ppo_batch& B, float* xt0, float* xt1,
-                                         float* xt2, float* g1, float* g2, float* gh, float* partials, float* smem) {
-  constexpr int NOUT = ACTOR ? A : 1;
-  using NL = NetLds<O, NOUT>;
-  const NL net{smem};
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 256 + threadIdx.x, m = B.m;
-  float* hb = smem + ((NetLds<O, A>::FLOATS + 3) & ~3) + wv * (H * 64);     // this wavefront's [unit][lane] bounce buffer
-  const bool on = row < m;
-  const int r = on ? row : m - 1;                       // (rows past the end recompute the last row and store nothing)
-  net.stage(w0, b0, w1, b1, wh, bh);
-  const long long s = B.perm[*B.offset + r];
-  const float inv_m = 1.0f / (float)m;
-  float x[O];
-  load_row<O>(B.obs + (size_t)s * O, x);
-  if (!ACTOR && on) {
-#pragma unroll
-    for (int i = 0; i < O; ++i) xt0[(size_t)i * m + row] = x[i];
-  }
-  __syncthreads();
-  // a layer's outputs are produced unit by unit in a run-time loop, but the next layer wants them as a register vector:
-  // they bounce through LDS (and leave for the weight-gradient GEMMs on the way)
-  float h[H];
-  dense<O, true>(x, net.w0(), net.b0(), 0, H, [&](int j, float v) { hb[j * 64 + lane] = v; if (on) xt1[(size_t)j * m + row] = v; });
-#pragma unroll
-  for (int j = 0; j < H; ++j) h[j] = hb[j * 64 + lane];
-  dense<H, true>(h, net.w1(), net.b1(), 0, H, [&](int j, float v) { hb[j * 64 + lane] = v; if (on) xt2[(size_t)j * m + row] = v; });
-#pragma unroll
-  for (int j = 0; j < H; ++j) h[j] = hb[j * 64 + lane];                      // h = h2 from here on
-  float* P_ = partials + (size_t)(row >> 6) * (3 + A);
-  auto raw = [&](int k, float v) { hb[k * 64 + lane] = v; };
-  float out[NOUT];
-  dense_head<NOUT>(h, net.wh(), net.bh(), out);
-  if constexpr (!ACTOR) {
-    const float v = out[0];
-    const float ret = B.ret[s], vp = B.vpred[s];
-    const float u = v - ret;
-    float vl, gv;
-    if (B.clipped_value) {                                       // ppo.py:61-66
-      const float dvp = v - vp;
-      const float wv_ = vp + fminf(fmaxf(dvp, -B.clip), B.clip) - ret;
-      const float ins = (dvp >= -B.clip && dvp <= B.clip) ? 1.0f : 0.0f;
-      const float uu = u * u, ww = wv_ * wv_;
-      vl = 0.5f * fmaxf(uu, ww);
-      gv = uu > ww ? u : (uu < ww ? wv_ * ins : 0.5f * (u + wv_ * ins));
-    } else { vl = 0.5f * u * u; gv = u; }                        // ppo.py:67-68
-    const float gout[1] = {on ? B.value_coef * gv * inv_m : 0.f};
-    if (on) gh[row] = gout[0];
-    const float svl = wave_sum(on ? vl : 0.f);
-    if (lane == 0 && on) P_[0] = svl;
-    dense_t<1>(gout, net.wh(), raw);
-  } else {
-    float z[A], e[A], lp = 0.f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      const float ls = logstd[a];
-      e[a] = expf(-ls);
-      z[a] = (B.actions[(size_t)s * A + a] - out[a]) * e[a];
-      lp += -0.5f * z[a] * z[a] - ls - HALF_LOG_2PI;
-    }
-    const float ratio = expf(lp - B.old_logp[s]), adv = B.adv[s];                                  // ppo.py:54-59
-    const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.0f - B.clip), 1.0f + B.clip) * adv;
-    const float inside = (ratio >= 1.0f - B.clip && ratio <= 1.0f + B.clip) ? 1.0f : 0.0f;
-    const float wsel = s1 < s2 ? 1.0f : (s1 > s2 ? inside : 0.5f * (1.0f + inside));
-    const float glp = on ? -adv * ratio * wsel * inv_m : 0.f;
-    float gout[A];
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      gout[a] = glp * z[a] * e[a];                                 // d logp / d mean_a = z / sigma
-      if (on) gh[(size_t)a * m + row] = gout[a];
-      const float sg = wave_sum(on ? glp * (z[a] * z[a] - 1.0f) : 0.f);       // d logp / d logstd_a = z^2 - 1
-      if (lane == 0 && on) P_[3 + a] = sg;
-    }
-    const float sal = wave_sum(on ? -fminf(s1, s2) : 0.f);
-    if (lane == 0 && on) { P_[1] = sal; P_[2] = (float)min(m - (row & ~63), 64); }
-    dense_t<A>(gout, net.wh(), raw);
-  }
-  // d loss / d pre-activation of layer 2 = (W_head^T g_head) * (1 - h2^2)
-  float d2[H];
-#pragma unroll
-  for (int k = 0; k < H; ++k) {
-    d2[k] = hb[k * 64 + lane] * (1.0f - h[k] * h[k]);
-    if (on) g2[(size_t)k * m + row] = d2[k];
-  }
-  // ... of layer 1 = (W1^T d2) * (1 - h1^2); h1 comes back from xt1 (this lane's own stores), requested before the products
-#pragma unroll
-  for (int k = 0; k < H; ++k) h[k] = xt1[(size_t)k * m + r];
-  dense_t<H>(d2, net.w1(), raw);
-#pragma unroll
-  for (int k = 0; k < H; ++k)
-    if (on) g1[(size_t)k * m + row] = hb[k * 64 + lane] * (1.0f - h[k] * h[k]);
-}
-
-template <int O, int A> constexpr size_t grad_smem_bytes() { return (size_t)(((NetLds<O, A>::FLOATS + 3) & ~3) + 4 * H * 64) * sizeof(float); }
-
-template <int O, int A>
-__global__ void __launch_bounds__(256)
-ppo_grad_stage1_kernel(CRITIC_ARGS, ACTOR_ARGS, const solorl_ppo_batch B, const solorl_ppo_stage1 W) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (blockIdx.y == 0) grad_net<O, A, false>(cw0, cb0, cw1, cb1, cwh, cbh, nullptr, B, W.xt0, W.c_xt1, W.c_xt2, W.c_g1, W.c_g2, W.c_gh, W.partials, smem);
-  else grad_net<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, B, W.xt0, W.a_xt1, W.a_xt2, W.a_g1, W.a_g2, W.a_gh, W.partials, smem);
-}
-
-// ------------------------------------------------------------------------------------------------ mini-batch gradients, stage 2
-// Weight gradients d W[u][k] = sum_r G[u][r] X[k][r] of the six layers from stage 1's [unit][row] arrays (X carries a row of
-// ones, so column K of the product is the bias gradient).  One wavefront per tile of 8 x 8 outputs and a chunk of CHUNK rows:
-// lane = row again -- sixteen coalesced loads feed 64 multiply-adds per row step -- then a halving butterfly leaves lane l with the
-// chunk's total of output l.  Chunk partials go to scratch and are added by stage 3 in a fixed order (deterministic, no atomics).
-constexpr int TB = 8, CHUNK = 4096;
+// ------------------------------------------------------------------------------------------------ stage 2 / 3 bookkeeping
+// Stage 2 (MFMA, below) leaves per-chunk partial products in scratch; stage 3 adds them in a fixed order (reproducible, no
+// atomics) straight into the parameters' gradients.  X carries a row of ones, so column K of a product is the bias gradient.
 struct LayerDesc { const float* g; const float* x; float* wgrad; float* bgrad; int U, K1, off, tile0; };   // K1 = inputs + 1
 struct Stage2Args { LayerDesc L[6]; int m, nchunks, total, ntiles; float* scratch; };
-
-__global__ void __launch_bounds__(256) ppo_grad_stage2_kernel(const Stage2Args S) {
-  // a workgroup = four wavefronts on 2 x 2 neighbouring tiles of the same row chunk: the G rows and X rows each of them streams
-  // are also streamed by one neighbour at the same time, i.e. they hit in the CU's L1 (the kernel is bound by L2 traffic)
-  int li = 0;
-#pragma unroll
-  for (int i = 1; i < 6; ++i) if ((int)blockIdx.x >= S.L[i].tile0) li = i;
-  const LayerDesc& L = S.L[li];
-  const int kb = (L.K1 + TB - 1) / TB, ub = (L.U + TB - 1) / TB, kb2 = (kb + 1) / 2, ub2 = (ub + 1) / 2;
-  const int t = blockIdx.x - L.tile0, wv = threadIdx.x >> 6;
-  const int chunk = t / (ub2 * kb2), tt = t % (ub2 * kb2), ut = 2 * (tt / kb2) + (wv >> 1), kt = 2 * (tt % kb2) + (wv & 1);
-  if (ut >= ub || kt >= kb) return;
-  const int u0 = ut * TB, k0 = kt * TB;
-  const int lane = threadIdx.x & 63, m = S.m;
-  const int r0 = chunk * CHUNK, r1 = min(r0 + CHUNK, m);
-  float acc[TB * TB];
-#pragma unroll
-  for (int i = 0; i < TB * TB; ++i) acc[i] = 0.f;
-  // rows of the tile that exist (a tile may hang over the edge of the layer): clamp the index, zero the factor
-  const float* gp[TB]; const float* xp[TB]; float gm[TB], xm[TB];
-#pragma unroll
-  for (int i = 0; i < TB; ++i) {
-    gm[i] = u0 + i < L.U ? 1.f : 0.f; gp[i] = L.g + (size_t)min(u0 + i, L.U - 1) * m;
-    xm[i] = k0 + i < L.K1 ? 1.f : 0.f; xp[i] = L.x + (size_t)min(k0 + i, L.K1 - 1) * m;
-  }
-#pragma unroll 2
-  for (int r = r0 + lane; r < r1; r += 64) {
-    float g[TB], x[TB];
-#pragma unroll
-    for (int i = 0; i < TB; ++i) { g[i] = gp[i][r] * gm[i]; x[i] = xp[i][r] * xm[i]; }
-#pragma unroll
-    for (int i = 0; i < TB; ++i)
-#pragma unroll
-      for (int j = 0; j < TB; ++j) acc[i * TB + j] = fmaf(g[i], x[j], acc[i * TB + j]);
-  }
-  // butterfly: after the step with distance d a lane keeps the half of its values whose index has bit d equal to its own
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const bool up = (lane & d) != 0;
-#pragma unroll
-    for (int i = 0; i < d; ++i) {
-      const float keep = up ? acc[i + d] : acc[i], send = up ? acc[i] : acc[i + d];
-      acc[i] = keep + __shfl_xor(send, d, 64);
-    }
-  }
-  const int i = lane / TB, j = lane % TB;                   // lane l now holds output l = i * 8 + j of the tile
-  if (u0 + i < L.U && k0 + j < L.K1) S.scratch[(size_t)chunk * S.total + L.off + (u0 + i) * L.K1 + (k0 + j)] = acc[0];
-}
 
 // stage 3: add the chunks (fixed order) into the parameters' gradients; the last block finishes the log-std gradient and the
 // running loss sums from stage 1's per-wavefront partials
@@ -440,10 +74,352 @@ __global__ void __launch_bounds__(256) ppo_grad_stage3_kernel(const Stage3Args T
 #pragma unroll
   for (int i = 1; i < 6; ++i) if (e >= S.L[i].off) li = i;
   const LayerDesc& L = S.L[li];
-  float a = 0.f;
-  for (int c = 0; c < S.nchunks; ++c) a += S.scratch[(size_t)c * S.total + e];
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};                       // four interleaved sums: the loads of a group are independent
+  int c = 0;
+  for (; c + 4 <= S.nchunks; c += 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] += S.scratch[(size_t)(c + i) * S.total + e];
+  }
+  for (; c < S.nchunks; ++c) a4[0] += S.scratch[(size_t)c * S.total + e];
+  const float a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   const int q = e - L.off, u = q / L.K1, k = q % L.K1;
   if (k == L.K1 - 1) L.bgrad[u] = a; else L.wgrad[u * (L.K1 - 1) + k] = a;
+}
+
+// ================================================================================================ MFMA formulation
+// act and stage 1 on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32, D[32x32] += A[32x2] B[2x32], 64 cycles).
+// Orientation: M = units, N = rows, i.e. every product is W . X^T.  Lane l = (c = l & 31, h = l >> 5):
+//   A operand  lane holds A[i = c][k = h]      -> a WEIGHT element W[unit 32 mt + c][input ...]
+//   B operand  lane holds B[k = h][j = c]      -> an ACTIVATION element of row c of the 32-row tile
+//   D          lane holds D[i = 8 (v >> 2) + 4 h + (v & 3)][j = c] in register v = 0..15
+// so a lane's 16 results belong to ITS row c and to the units {8 q + 4 h + t}.  A step of the NEXT layer contracts over two
+// units, one from each lane half; taking them as (8 q + t) from half 0 and (8 q + 4 + t) from half 1 makes the next layer's B
+// operand for step (q, t) exactly register v = 4 q' + t of the previous D (q' = q mod 4, tile mt = q / 4): activations never
+// leave their registers between layers, forward or backward, and there is no LDS in these kernels.  The matching A element
+// is W[unit 32 mt + c][input 8 q + 4 h + t]: a lane reads 16 consecutive bytes of one weight row per q -- all weights of a net
+// (forward and transposed, 256 VGPRs) are loaded once per wavefront and stay in registers while it walks over its row tiles.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int O, int NOUT, bool BACKWARD> struct NetRegs {
+  static constexpr int QO = (O + 7) / 8, QA = (NOUT + 7) / 8;
+  float a0[2][QO][4], a1[2][8][4], ah[8][4];
+  float aht[BACKWARD ? 2 : 1][QA][4], a1t[BACKWARD ? 2 : 1][BACKWARD ? 8 : 1][4];
+  __device__ __forceinline__ void load(NET_ARGS, int c, int h) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int q = 0; q < QO; ++q) {
+        const int i0 = 8 * q + 4 * h;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 < O) v = *reinterpret_cast<const float4*>(w0 + (size_t)(32 * mt + c) * O + i0);       // (O % 4 == 0: a chunk is in or out)
+        a0[mt][q][0] = v.x; a0[mt][q][1] = v.y; a0[mt][q][2] = v.z; a0[mt][q][3] = v.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(w1 + (32 * mt + c) * H + 8 * q + 4 * h);
+        a1[mt][q][0] = v.x; a1[mt][q][1] = v.y; a1[mt][q][2] = v.z; a1[mt][q][3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < NOUT) v = *reinterpret_cast<const float4*>(wh + c * H + 8 * q + 4 * h);
+      ah[q][0] = v.x; ah[q][1] = v.y; ah[q][2] = v.z; ah[q][3] = v.w;
+    }
+    if constexpr (BACKWARD) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int q = 0; q < QA; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { const int a = 8 * q + 4 * h + t; aht[mt][q][t] = a < NOUT ? wh[a * H + 32 * mt + c] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a1t[mt][q][t] = w1[(8 * q + 4 * h + t) * H + 32 * mt + c];
+      }
+    }
+  }
+};
+
+// the unit a D register belongs to
+__device__ __forceinline__ constexpr int unit_of(int mt, int v, int h) { return 32 * mt + 8 * (v >> 2) + 4 * h + (v & 3); }
+
+// layers 1 and 2 and the head for one 32-row tile; x = the lane's row, inputs 8 q + 4 h .. + 3 per q.  After the call h1, h2 hold
+// tanh activations (D layout), dh the head outputs (unit = unit_of(0, v, h), valid below NOUT).
+template <int O, int NOUT, bool BW, typename S1, typename S2>
+__device__ __forceinline__ void mfma_forward(const NetRegs<O, NOUT, BW>& R, const float* __restrict__ b0, const float* __restrict__ b1,
+                                             const float* __restrict__ bh, const float* __restrict__ xrow, int h, f32x16 (&h1)[2],
+                                             f32x16 (&h2)[2], f32x16& dh, S1&& store_x, S2&& store_h) {
+  constexpr int QO = NetRegs<O, NOUT, BW>::QO;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { h1[mt][v] = b0[unit_of(mt, v, h)]; h2[mt][v] = b1[unit_of(mt, v, h)]; }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { const int a = unit_of(0, v, h); dh[v] = a < NOUT ? bh[a] : 0.f; }
+#pragma unroll
+  for (int q = 0; q < QO; ++q) {
+    const int i0 = 8 * q + 4 * h;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 < O) xv = *reinterpret_cast<const float4*>(xrow + i0);
+    const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (i0 < O) store_x(i0, x);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      h1[0] = MFMA32(R.a0[0][q][t], x[t], h1[0]);
+      h1[1] = MFMA32(R.a0[1][q][t], x[t], h1[1]);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) h1[mt][v] = tanhf(h1[mt][v]);
+  store_h(1, h1);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      h2[0] = MFMA32(R.a1[0][4 * mt + (v >> 2)][v & 3], h1[mt][v], h2[0]);
+      h2[1] = MFMA32(R.a1[1][4 * mt + (v >> 2)][v & 3], h1[mt][v], h2[1]);
+    }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) h2[mt][v] = tanhf(h2[mt][v]);
+  store_h(2, h2);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dh = MFMA32(R.ah[4 * mt + (v >> 2)][v & 3], h2[mt][v], dh);
+}
+
+// ---------------------------------------------------------------- act on MFMA: grid (ceil(n / 32), 2), one wavefront per 32 rows
+template <int O, int A, bool ACTOR>
+__device__ __forceinline__ void act_net_mfma(NET_ARGS, const float* __restrict__ logstd, const float* __restrict__ obs,
+                                             const float* __restrict__ noise, int n, float* value_out, float* action_out, float* logp_out) {
+  constexpr int NOUT = ACTOR ? A : 1;
+  const int l = threadIdx.x, c = l & 31, h = l >> 5, row = blockIdx.x * 32 + c;
+  const bool on = row < n;
+  const int r = on ? row : n - 1;
+  NetRegs<O, NOUT, false> R;
+  R.load(w0, b0, w1, b1, wh, bh, c, h);
+  f32x16 h1[2], h2[2], dh;
+  mfma_forward<O, NOUT, false>(R, b0, b1, bh, obs + (size_t)r * O, h, h1, h2, dh, [](int, const float (&)[4]) {}, [](int, f32x16 (&)[2]) {});
+  if constexpr (!ACTOR) {
+    if (on && h == 0) value_out[row] = dh[0];
+  } else {
+    float lp = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int a = unit_of(0, v, h);
+      if (a < A && (8 * (v >> 2) + (v & 3)) < A) {              // (second test: compile-time bound on v; first: this half's unit)
+        const float mean = dh[v], ls = logstd[a];
+        const float act = noise ? fmaf(expf(ls), noise[(size_t)r * A + a], mean) : mean;       // policy.py:40-43
+        const float z = (act - mean) * expf(-ls);                                              // ModNormal.log_probs, policy.py:171-173
+        lp += -0.5f * z * z - ls - HALF_LOG_2PI;
+        if (on) action_out[(size_t)row * A + a] = act;
+      }
+    }
+    lp += __shfl_xor(lp, 32, 64);                                // the row's other action dims live in the other lane half
+    if (on && h == 0) logp_out[row] = lp;
+  }
+}
+
+template <int O, int A>
+__global__ void __launch_bounds__(64)
+policy_act_mfma_kernel(CRITIC_ARGS, ACTOR_ARGS, const float* __restrict__ obs, const float* __restrict__ noise, int n, float* value_out,
+                       float* action_out, float* logp_out) {
+  if (blockIdx.y == 0) act_net_mfma<O, A, false>(cw0, cb0, cw1, cb1, cwh, cbh, nullptr, obs, noise, n, value_out, action_out, logp_out);
+  else act_net_mfma<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, obs, noise, n, value_out, action_out, logp_out);
+}
+
+// ---------------------------------------------------------------- stage 1 on MFMA: grid (ceil(m / 64), 2), one wavefront walks two
+// 32-row tiles (= rows 64 b .. 64 b + 63, so partials keep one row per 64 samples) with its net's weights resident
+template <int O, int A, bool ACTOR>
+__device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict__ logstd, const solorl_ppo_batch& B, float* xt0, float* xt1,
+                                              float* xt2, float* g1, float* g2, float* gh, float* partials) {
+  constexpr int NOUT = ACTOR ? A : 1;
+  using NR = NetRegs<O, NOUT, true>;
+  const int l = threadIdx.x, c = l & 31, h = l >> 5, m = B.m;
+  NR R;
+  R.load(w0, b0, w1, b1, wh, bh, c, h);
+  const float inv_m = 1.0f / (float)m;
+  float loss_acc = 0.f, gls_acc[ACTOR ? 16 : 1] = {};
+  int rows_here = 0;
+#pragma unroll 1
+  for (int tile = 0; tile < 2; ++tile) {
+    const int row = blockIdx.x * 64 + tile * 32 + c;
+    if (blockIdx.x * 64 + tile * 32 >= m) break;
+    const bool on = row < m;
+    const int r = on ? row : m - 1;
+    rows_here += min(m - (blockIdx.x * 64 + tile * 32), 32);
+    const long long s = B.perm[*B.offset + r];
+    f32x16 h1[2], h2[2], dh;
+    auto store_units = [&](float* arr, f32x16 (&a)[2]) {
+      if (on) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) arr[(size_t)unit_of(mt, v, h) * m + row] = a[mt][v];
+      }
+    };
+    mfma_forward<O, NOUT, true>(R, b0, b1, bh, B.obs + (size_t)s * O, h, h1, h2, dh,
+        [&](int i0, const float (&x)[4]) {
+          if (!ACTOR && on) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xt0[(size_t)(i0 + t) * m + row] = x[t];
+          }
+        },
+        [&](int layer, f32x16 (&a)[2]) { store_units(layer == 1 ? xt1 : xt2, a); });
+    // head gradient in the head's D layout: register v <-> unit 8 (v >> 2) + 4 h + (v & 3)
+    f32x16 gout;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) gout[v] = 0.f;
+    if constexpr (!ACTOR) {
+      const float v_ = dh[0], ret = B.ret[s], vp = B.vpred[s];
+      const float u = v_ - ret;
+      float vl, gv;
+      if (B.clipped_value) {                                       // ppo.py:61-66
+        const float dvp = v_ - vp;
+        const float wv_ = vp + fminf(fmaxf(dvp, -B.clip), B.clip) - ret;
+        const float ins = (dvp >= -B.clip && dvp <= B.clip) ? 1.0f : 0.0f;
+        const float uu = u * u, ww = wv_ * wv_;
+        vl = 0.5f * fmaxf(uu, ww);
+        gv = uu > ww ? u : (uu < ww ? wv_ * ins : 0.5f * (u + wv_ * ins));
+      } else { vl = 0.5f * u * u; gv = u; }                        // ppo.py:67-68
+      const bool mine = on && h == 0;                              // unit 0 lives in lane half 0
+      gout[0] = mine ? B.value_coef * gv * inv_m : 0.f;
+      if (mine) { gh[row] = gout[0]; loss_acc += vl; }
+    } else {
+      float z[16], e[16], lp = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int a = unit_of(0, v, h);
+        z[v] = 0.f; e[v] = 0.f;
+        if ((8 * (v >> 2) + (v & 3)) < A && a < A) {
+          const float ls = logstd[a];
+          e[v] = expf(-ls);
+          z[v] = (B.actions[(size_t)s * A + a] - dh[v]) * e[v];
+          lp += -0.5f * z[v] * z[v] - ls - HALF_LOG_2PI;
+        }
+      }
+      lp += __shfl_xor(lp, 32, 64);
+      const float ratio = expf(lp - B.old_logp[s]), adv = B.adv[s];                                  // ppo.py:54-59
+      const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.0f - B.clip), 1.0f + B.clip) * adv;
+      const float inside = (ratio >= 1.0f - B.clip && ratio <= 1.0f + B.clip) ? 1.0f : 0.0f;
+      const float wsel = s1 < s2 ? 1.0f : (s1 > s2 ? inside : 0.5f * (1.0f + inside));
+      const float glp = on ? -adv * ratio * wsel * inv_m : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int a = unit_of(0, v, h);
+        if ((8 * (v >> 2) + (v & 3)) < A && a < A) {
+          gout[v] = glp * z[v] * e[v];                               // d logp / d mean_a = z / sigma
+          if (on) gh[(size_t)a * m + row] = gout[v];
+          gls_acc[v] += glp * (z[v] * z[v] - 1.0f);                  // d logp / d logstd_a = z^2 - 1
+        }
+      }
+      if (on && h == 0) loss_acc += -fminf(s1, s2);
+    }
+    // back through the head, layer 2, layer 1: the same register-to-operand identity as forward
+    f32x16 d2[2], d1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { d2[mt][v] = 0.f; d1[mt][v] = 0.f; }
+#pragma unroll
+    for (int v = 0; v < 4 * NR::QA; ++v) {
+      d2[0] = MFMA32(R.aht[0][v >> 2][v & 3], gout[v], d2[0]);
+      d2[1] = MFMA32(R.aht[1][v >> 2][v & 3], gout[v], d2[1]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) d2[mt][v] *= 1.0f - h2[mt][v] * h2[mt][v];
+    store_units(g2, d2);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        d1[0] = MFMA32(R.a1t[0][4 * mt + (v >> 2)][v & 3], d2[mt][v], d1[0]);
+        d1[1] = MFMA32(R.a1t[1][4 * mt + (v >> 2)][v & 3], d2[mt][v], d1[1]);
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) d1[mt][v] *= 1.0f - h1[mt][v] * h1[mt][v];
+    store_units(g1, d1);
+  }
+  // this wavefront's row of partials: sums over its 64 rows
+  float* P_ = partials + (size_t)blockIdx.x * (3 + A);
+  const float tot = wave_sum(loss_acc);
+  if constexpr (!ACTOR) {
+    if (l == 0) P_[0] = tot;
+  } else {
+    if (l == 0) { P_[1] = tot; P_[2] = (float)rows_here; }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      if ((8 * (v >> 2) + (v & 3)) < A) {
+        float sg = gls_acc[v];                                      // sum over the 32 lanes of this half (the unit differs per half)
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) sg += __shfl_xor(sg, d, 64);
+        const int a = unit_of(0, v, h);
+        if (c == 0 && a < A) P_[3 + a] = sg;
+      }
+    }
+  }
+}
+
+template <int O, int A>
+__global__ void __launch_bounds__(64)
+ppo_grad_stage1_mfma_kernel(CRITIC_ARGS, ACTOR_ARGS, const solorl_ppo_batch B, const solorl_ppo_stage1 W) {
+  if (blockIdx.y == 0) grad_net_mfma<O, A, false>(cw0, cb0, cw1, cb1, cwh, cbh, nullptr, B, W.xt0, W.c_xt1, W.c_xt2, W.c_g1, W.c_g2, W.c_gh, W.partials);
+  else grad_net_mfma<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, B, W.xt0, W.a_xt1, W.a_xt2, W.a_g1, W.a_g2, W.a_gh, W.partials);
+}
+
+// ---------------------------------------------------------------- stage 2 on MFMA: d W = G . X^T with the ROW index as K
+// One wavefront per (layer, 32-unit tile of G, 32-unit tile of X, chunk of MCHUNK rows).  Lane (c, h) reads 16 consecutive bytes
+// = rows r .. r + 3 of ITS unit's row of G (A operand) and of X (B operand), half h taking rows r0 + 4 h ..: four MFMA steps per
+// pair of loads, each step contracting one row from either half.  D register v of lane (c, h) is
+// d W[unit 32 mt + 8 (v >> 2) + 4 h + (v & 3)][input 32 nt + c]: stores are contiguous along the input index.
+constexpr int MCHUNK = 512;
+__global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Args S) {
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < 6; ++i) if ((int)blockIdx.x >= S.L[i].tile0) li = i;
+  const LayerDesc& L = S.L[li];
+  const int ntn = (L.K1 + 31) / 32, ntm = (L.U + 31) / 32;
+  const int t = blockIdx.x - L.tile0, chunk = t / (ntm * ntn), tt = t % (ntm * ntn), mt = tt / ntn, nt = tt % ntn;
+  const int l = threadIdx.x, c = l & 31, h = l >> 5, m = S.m;
+  const int ua = 32 * mt + c, ub = 32 * nt + c;
+  const bool va = ua < L.U, vb = ub < L.K1;
+  const float* __restrict__ ga = L.g + (size_t)(va ? ua : 0) * m;
+  const float* __restrict__ xb = L.x + (size_t)(vb ? ub : 0) * m;
+  const int r0 = chunk * MCHUNK, r1 = min(r0 + MCHUNK, m);
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  // (m is a multiple of 64: whole float4s, both halves always in range and on the same trip count.)  The loads of the next two
+  // steps are in flight while a step's four MFMAs run: a lone wavefront has nobody else to hide the L2 latency behind
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto lda = [&](int r) { return (va && r < r1) ? *reinterpret_cast<const float4*>(ga + r) : zero4; };
+  auto ldb = [&](int r) { return (vb && r < r1) ? *reinterpret_cast<const float4*>(xb + r) : zero4; };
+  int r = r0 + 4 * h;
+  float4 a0 = lda(r), b0 = ldb(r), a1 = lda(r + 8), b1 = ldb(r + 8);
+#pragma unroll 1
+  for (; r < r1; r += 16) {
+    const float4 a2 = lda(r + 16), b2 = ldb(r + 16), a3 = lda(r + 24), b3 = ldb(r + 24);
+    acc = MFMA32(a0.x, b0.x, acc); acc = MFMA32(a0.y, b0.y, acc); acc = MFMA32(a0.z, b0.z, acc); acc = MFMA32(a0.w, b0.w, acc);
+    acc = MFMA32(a1.x, b1.x, acc); acc = MFMA32(a1.y, b1.y, acc); acc = MFMA32(a1.z, b1.z, acc); acc = MFMA32(a1.w, b1.w, acc);
+    a0 = a2; b0 = b2; a1 = a3; b1 = b3;
+  }
+  float* out = S.scratch + (size_t)chunk * S.total + L.off;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int u = 32 * mt + 8 * (v >> 2) + 4 * h + (v & 3);
+    if (u < L.U && vb) out[u * L.K1 + ub] = acc[v];
+  }
 }
 
 template <typename F> int dispatch_dims(int O, int A, F&& f) {
@@ -479,10 +455,9 @@ int solorl_policy_act(const solorl_policy_params* p, const float* obs, const flo
   const solorl_policy_params P = *p;
   return dispatch_dims(P.obs_dim, P.act_dim, [&](auto oc, auto ac) {
     constexpr int O = decltype(oc)::value, A = decltype(ac)::value;
-    constexpr size_t smem = act_smem_bytes<O, A>();
-    hipLaunchKernelGGL((policy_act_kernel<O, A>), dim3((n + 63) / 64, 2), dim3(256), smem, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, obs, noise,
+    hipLaunchKernelGGL((policy_act_mfma_kernel<O, A>), dim3((n + 31) / 32, 2), dim3(64), 0, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, obs, noise,
                        n, value_out, action_out, logp_out);
-    return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "policy_act_kernel launch");
+    return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "policy_act_mfma_kernel launch");
   });
 }
 
@@ -499,16 +474,8 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
   const solorl_ppo_stage1 W = *work;
   return dispatch_dims(P.obs_dim, P.act_dim, [&](auto oc, auto ac) {
     constexpr int O = decltype(oc)::value, A = decltype(ac)::value;
-    constexpr size_t smem = grad_smem_bytes<O, A>();                 // 39 KB of weights + 4 x 16 KB: above the 64 KB default
-    static bool raised[16] = {};                                     // per device: once is enough (and keeps captures free of it)
-    if (device_id < 16 && !raised[device_id]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_grad_stage1_kernel<O, A>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)smem) != hipSuccess)
-        return solorl_fail_(SOLORL_ERR_HIP, "hipFuncSetAttribute(ppo_grad_stage1_kernel)");
-      raised[device_id] = true;
-    }
-    hipLaunchKernelGGL((ppo_grad_stage1_kernel<O, A>), dim3((B.m + 255) / 256, 2), dim3(256), smem, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, B, W);
-    return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage1_kernel launch");
+    hipLaunchKernelGGL((ppo_grad_stage1_mfma_kernel<O, A>), dim3((B.m + 63) / 64, 2), dim3(64), 0, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, B, W);
+    return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage1_mfma_kernel launch");
   });
 }
 
@@ -529,17 +496,18 @@ int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage
       {work->c_g1, work->xt0, out->critic_w0, out->critic_b0, H, O + 1, 0, 0}, {work->c_g2, work->c_xt1, out->critic_w1, out->critic_b1, H, H + 1, 0, 0},
       {work->c_gh, work->c_xt2, out->critic_w2, out->critic_b2, 1, H + 1, 0, 0}, {work->a_g1, work->xt0, out->actor_w0, out->actor_b0, H, O + 1, 0, 0},
       {work->a_g2, work->a_xt1, out->actor_w1, out->actor_b1, H, H + 1, 0, 0}, {work->a_gh, work->a_xt2, out->mean_w, out->mean_b, A, H + 1, 0, 0}};
-  S.m = m; S.nchunks = (m + CHUNK - 1) / CHUNK; S.scratch = out->scratch;
+  if (m % 64 != 0) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage2: m must be a multiple of 64 rows");
+  S.m = m; S.nchunks = (m + MCHUNK - 1) / MCHUNK; S.scratch = out->scratch;
   int off = 0, tile = 0;
   for (int i = 0; i < 6; ++i) {
     S.L[i] = L[i]; S.L[i].off = off; S.L[i].tile0 = tile;
     off += L[i].U * L[i].K1;
-    tile += (((L[i].U + TB - 1) / TB + 1) / 2) * (((L[i].K1 + TB - 1) / TB + 1) / 2) * S.nchunks;       // workgroups of 2 x 2 tiles
+    tile += ((L[i].U + 31) / 32) * ((L[i].K1 + 31) / 32) * S.nchunks;
   }
   S.total = off; S.ntiles = tile;
   T.partials = work->partials; T.nwaves = (m + 63) / 64; T.A = A; T.logstd = p->logstd; T.logstd_grad = out->logstd;
   T.loss_sums = out->loss_sums; T.logstd_sum = out->logstd_sum; T.entropy_coef = out->entropy_coef;
-  hipLaunchKernelGGL(ppo_grad_stage2_kernel, dim3(S.ntiles), dim3(256), 0, (hipStream_t)stream, S);
+  hipLaunchKernelGGL(ppo_grad_stage2_mfma_kernel, dim3(S.ntiles), dim3(64), 0, (hipStream_t)stream, S);
   hipLaunchKernelGGL(ppo_grad_stage3_kernel, dim3((S.total + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, T);
   return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage2/3 launch");
 }

@@ -142,7 +142,7 @@ class MiniBatchGrad:
         self.psum = torch.zeros(3 + A, device=dev)          # running sums of the partials over the steps of an update
         self.ent = torch.zeros(1, device=dev)               # running sum of sum_a logstd_a
         L = _native.lib()
-        self.scratch = torch.zeros(((m + 4095) // 4096) * L.solorl_ppo_grad_count(O, A), device=dev)
+        self.scratch = torch.zeros(((m + 511) // 512) * L.solorl_ppo_grad_count(O, A), device=dev)
         G = self.G = _native.PpoGrads()
         grads = {"critic_w0": b.critic[0].weight, "critic_b0": b.critic[0].bias, "critic_w1": b.critic[2].weight, "critic_b1": b.critic[2].bias,
                  "critic_w2": b.critic[4].weight, "critic_b2": b.critic[4].bias, "actor_w0": b.features[0].weight, "actor_b0": b.features[0].bias,
