@@ -50,19 +50,21 @@ class GraphedRollout:
         st = self.storage
         assert st.step == 0, "graphed rollouts start at storage step 0"
         # the arithmetic of train.rollout() with every result written where it is stored: the policy's outputs and the engine's
-        # observations / rewards go straight into the storage rows (the C ABI takes caller-owned pointers), masks = 1 - done in
-        # one launch -- 19 launches per step instead of 35, and launches are what a step costs besides the env kernel
-        one = torch.ones((), device=st.device)
+        # observations / rewards / done flags go straight into storage-side rows (the C ABI takes caller-owned pointers) -- two
+        # launches per step (act, env step) instead of 35, and launches are what a step costs besides the env kernel
         fused = policy_kernels_supported(self.ac)
-        if fused:                            # one launch for the whole of Policy.act (csrc/solorl_ppo.hip) + one for the noise
+        if fused:                            # one launch for the whole of Policy.act (csrc/solorl_ppo.hip)
             self._pp = policy_params(self.ac)
+        # the normal draws of all T steps and masks = 1 - done of all T steps are one launch each per rollout, not per step
+        noise = torch.randn_like(st.actions) if fused else None
+        done = torch.empty(self.T, st.num_agents, dtype=torch.uint8, device=st.device)
         for t in range(self.T):
             if fused:
-                policy_act(self._pp, st.obs[t], torch.randn_like(st.actions[t]), st.value_preds[t], st.actions[t], st.action_log_probs[t])
+                policy_act(self._pp, st.obs[t], noise[t], st.value_preds[t], st.actions[t], st.action_log_probs[t])
             else:
                 self.ac.act_into(st.obs[t], st.value_preds[t], st.actions[t], st.action_log_probs[t])
-            _, _, done, _ = self.envs.step_inplace(st.actions[t], obs_out=st.obs[t + 1], rew_out=st.rewards[t])
-            torch.sub(one, done, out=st.masks[t + 1].view(-1))
+            self.envs.step_inplace(st.actions[t], obs_out=st.obs[t + 1], rew_out=st.rewards[t], done_out=done[t])
+        torch.sub(torch.ones((), device=st.device), done, out=st.masks[1:].view(self.T, st.num_agents))
 
     def _capturable(self):
         # contact-count sorting (opt-in, SOLORL_SORT=1) ping-pongs two state buffers on the host side of

@@ -160,18 +160,21 @@ class SoloVecEnv:
                 name, list(shape), self.device, x.dtype, tuple(x.shape), x.device))
         return C.c_void_p(x.data_ptr())
 
-    def step_inplace(self, actions, obs_out=None, rew_out=None):
+    def step_inplace(self, actions, obs_out=None, rew_out=None, done_out=None):
         """Zero-copy variant for rollout loops: returns views of the engine-owned output buffers (overwritten by the next
-        step) -- or writes observations [N, O] / rewards [N] or [N, 1] straight into caller-owned tensors such as rollout-storage
-        rows (the C ABI takes the caller's pointers anyway).  Host-side checks only, capturable in a HIP graph."""
+        step) -- or writes observations [N, O] / rewards [N] or [N, 1] / done flags (uint8 [N]) straight into caller-owned tensors
+        such as rollout-storage rows (the C ABI takes the caller's pointers anyway).  Host-side checks only, capturable in a HIP graph."""
         a = self._raw("actions", actions, (self.nenvs, self.act_dim))
         o = self._obs if obs_out is None else obs_out
         r = self._rew if rew_out is None else rew_out
         po = self._raw("obs_out", o, (self.nenvs, self.obs_dim))
         pr = self._raw("rew_out", r, tuple(r.shape) if tuple(r.shape) in ((self.nenvs,), (self.nenvs, 1)) else (self.nenvs,))
+        d = self._done if done_out is None else done_out
+        if not (d.is_cuda and d.device == self.device and d.dtype == torch.uint8 and d.is_contiguous() and tuple(d.shape) == (self.nenvs,)):
+            raise AssertionError("done_out must be a contiguous uint8 [%d] tensor on %s" % (self.nenvs, self.device))
         with torch.cuda.device(self.device):
-            _native.check(self.L.solorl_step(self._h, a, po, pr, C.c_void_p(self._done.data_ptr()), C.byref(self._info_c), self._stream()))
-        return o, r, self._done, self._info
+            _native.check(self.L.solorl_step(self._h, a, po, pr, C.c_void_p(d.data_ptr()), C.byref(self._info_c), self._stream()))
+        return o, r, d, self._info
 
     def get_observation(self):
         with torch.cuda.device(self.device):
