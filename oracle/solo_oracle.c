@@ -308,12 +308,31 @@ static void substep(oracle_env* E, int ei) {
   for (int k = 0; k < nv; k++) { u[k] += dt * udot[k]; clampv(&u[k], C->max_velocity); } /* K5 */
 
   /* --- constraint rows: joint limits, contact normals, friction (K7) */
-  row_t rows[MAX_ROWS]; int nr = 0, nlim = 0;
-  for (int j = 0; j < n && nlim < MAX_LIMITS; j++) {
-    for (int side = 0; side < 2 && nlim < MAX_LIMITS; side++) {
+  /* K5: at most MAX_LIMITS limit rows are solved -- the candidates (joint within LIMIT_WINDOW of a limit) with the SMALLEST
+   * margin, i.e. the most violated first (ties: lower joint, lower side), emitted in joint order.  (Until round 2 the first
+   * MAX_LIMITS in joint order were taken: a third joint could then run far past its limit unopposed and be thrown back at
+   * erp * violation / dt when a slot freed up -- robots launched metres into the air under a random policy.) */
+  row_t rows[MAX_ROWS]; int nr = 0;
+  int lim_sel[2 * SOLORL_MAX_DOF]; memset(lim_sel, 0, sizeof lim_sel);
+  {
+    double pens[2 * SOLORL_MAX_DOF]; int cand[2 * SOLORL_MAX_DOF], ncand = 0;
+    for (int j = 0; j < n; j++)
+      for (int side = 0; side < 2; side++) {
+        pens[2 * j + side] = side == 0 ? s->q[j] + C->joint_limit : C->joint_limit - s->q[j];
+        if (pens[2 * j + side] < LIMIT_WINDOW) cand[ncand++] = 2 * j + side;
+      }
+    for (int a = 0; a < ncand; a++) {
+      int rank = 0;
+      for (int b = 0; b < ncand; b++)
+        rank += pens[cand[b]] < pens[cand[a]] || (pens[cand[b]] == pens[cand[a]] && cand[b] < cand[a]);
+      lim_sel[cand[a]] = rank < MAX_LIMITS;
+    }
+  }
+  for (int j = 0; j < n; j++) {
+    for (int side = 0; side < 2; side++) {
+      if (!lim_sel[2 * j + side]) continue;
       double pen = side == 0 ? s->q[j] + C->joint_limit : C->joint_limit - s->q[j];
-      if (!(pen < LIMIT_WINDOW)) continue;
-      row_t* r = &rows[nr++]; nlim++;
+      row_t* r = &rows[nr++];
       memset(r, 0, sizeof *r);
       r->J[6 + j] = side == 0 ? 1.0 : -1.0; r->parent = -1; r->mu = 0;
       r->rhs = pen; /* stash penetration; finished below */

@@ -306,11 +306,11 @@ template <typename T, int ROBOT> struct SubCtx {
   M3<T> R0;
   V3<T> kneeP[4], footP[4], shP[4];
   T dist[NPRIM];
-  int mask, nc, nlim_total, nlim;
+  int mask, nc, nlim_total, lsel;  // lsel: the joint-limit rows that are solved, bit 2j = lower limit of joint j, 2j+1 = upper
   int smask; T tmy;                // treadmill: primitives whose support point lies on the strip; the strip's centre line
   ABI<T> Ibase; SV<T> pbase;
   ABI<T> Ileg[4]; SV<T> pleg[4];   // team mode: per-leg contributions, summed by the leader
-  int limoff[4];                   // team mode: first joint-limit slot of each leg
+  T limpen[2 * NQ];                // team mode: the joints' margins to their limits while more than MAX_LIMITS compete
   LegResp<T, NJ> LR[4];
   SV<T> ub; T qds[NQ];
   SV<T> w; T y[4][3]; T lam_n[12];   // (lane mode: normal impulses of primitives 12..23)
@@ -414,26 +414,32 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
   }
 #pragma unroll
   for (int p = 0; p < NPRIM; p++) C.dist[p] = dist[p];
-  int nl = 0;   // limit rows come first: their count fixes the contact slots
+  // joint-limit rows (K5) come first: their count fixes the contact slots.  At most MAX_LIMITS are solved: the candidates
+  // (joint within LIMIT_WINDOW of a limit) with the smallest margin, i.e. the most violated first (ties: lower joint, lower
+  // side).  Taking the first MAX_LIMITS in joint order instead (rounds 1-2) let a third joint run radians past its limit
+  // unopposed and be thrown back at erp * violation / dt once a slot freed up: robots were launched metres into the air.
+  T lpen[2 * NQ];
+  int lcand = 0;
 #pragma unroll
   for (int j = 0; j < NQ; j++) {
-    nl += (st.q[j] + pp.qlim < T(LIMIT_WINDOW)) ? 1 : 0;
-    nl += (pp.qlim - st.q[j] < T(LIMIT_WINDOW)) ? 1 : 0;
+    lpen[2 * j] = st.q[j] + pp.qlim; lpen[2 * j + 1] = pp.qlim - st.q[j];
+    if (lpen[2 * j] < T(LIMIT_WINDOW)) lcand |= 1 << (2 * j);
+    if (lpen[2 * j + 1] < T(LIMIT_WINDOW)) lcand |= 1 << (2 * j + 1);
   }
-  C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
-  C.smask = smask & mask;
-  {
-    int run = 0;
+  int lsel = lcand;
+  if (__popc(lcand) > MAX_LIMITS) {
+    lsel = 0;
 #pragma unroll
-    for (int L = 0; L < 4; L++) {
-      C.limoff[L] = run > MAX_LIMITS ? MAX_LIMITS : run;
+    for (int a = 0; a < 2 * NQ; a++) {
+      int rank = 0;
 #pragma unroll
-      for (int k = 0; k < RB::NJ; k++) {
-        run += (st.q[L * RB::NJ + k] + pp.qlim < T(LIMIT_WINDOW)) ? 1 : 0;
-        run += (pp.qlim - st.q[L * RB::NJ + k] < T(LIMIT_WINDOW)) ? 1 : 0;
-      }
+      for (int b = 0; b < 2 * NQ; b++)
+        if (b != a) rank += (((lcand >> b) & 1) && (lpen[b] < lpen[a] || (lpen[b] == lpen[a] && b < a))) ? 1 : 0;
+      if (((lcand >> a) & 1) && rank < MAX_LIMITS) lsel |= 1 << a;
     }
   }
+  C.mask = mask; C.nc = __popc(mask); C.nlim_total = __popc(lsel); C.lsel = lsel;
+  C.smask = smask & mask;
   // base link terms start the articulated-inertia accumulation
   constexpr solorl_link_data B = RB::MD.links[0];
   static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");
@@ -545,23 +551,22 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
     });
   });
   C.LR[L] = LR;
-  // joint-limit rows of this leg (K5): first MAX_LIMITS in joint order across the robot
-  int nlim = C.nlim;
+  // joint-limit rows of this leg (K5): the ones phase_detect selected, slots in joint order
+  const int lsel = C.lsel;
   static_for<NJ>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
 #pragma unroll
     for (int side = 0; side < 2; side++) {
-      T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
-      if (pen < T(LIMIT_WINDOW) && nlim < MAX_LIMITS) {
+      const int bit = 2 * (L * NJ + k) + side;
+      if ((lsel >> bit) & 1) {
+        T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
         T sg = side == 0 ? T(1) : T(-1);
         T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
         JL[k] = sg;
-        park_row(lds, nlim, LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
-        nlim++;
+        park_row(lds, __popc(lsel & ((1 << bit) - 1)), LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
       }
     }
   });
-  C.nlim = nlim;
   // contact rows of this leg's primitives: knee (chain depth NJ-1), foot (depth NJ) and, Solo12, the shoulder housing (depth 1)
   const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
   static_for<(RB::SHOULDER ? 3 : 2)>([&](auto ic) {
@@ -729,22 +734,24 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
     });
   });
   C.LR[L] = LR;
-  // joint-limit rows of this leg: slots from the per-leg offsets of phase_detect
-  int nlim = C.limoff[L];
-  static_for<NJ>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
+  // joint-limit rows of this leg: the ones the collision phase selected (C.lsel), slots in joint order
+  const int lsel = C.lsel;
+  if ((lsel >> (2 * NJ * L)) & ((1 << (2 * NJ)) - 1)) {
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
 #pragma unroll
-    for (int side = 0; side < 2; side++) {
-      T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
-      if (pen < T(LIMIT_WINDOW) && nlim < MAX_LIMITS) {
-        T sg = side == 0 ? T(1) : T(-1);
-        T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
-        JL[k] = sg;
-        park_row(lds, nlim, LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
-        nlim++;
+      for (int side = 0; side < 2; side++) {
+        const int bit = 2 * (L * NJ + k) + side;
+        if ((lsel >> bit) & 1) {
+          T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
+          T sg = side == 0 ? T(1) : T(-1);
+          T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
+          JL[k] = sg;
+          park_row(lds, __popc(lsel & ((1 << bit) - 1)), LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
+        }
       }
-    }
-  });
+    });
+  }
   // contact rows of this leg's primitives: knee (chain depth NJ-1), foot (depth NJ) and, Solo12, the shoulder housing (depth 1)
   const int mask = C.mask, nlt = C.nlim_total, nc = C.nc;
   static_for<(RB::SHOULDER ? 3 : 2)>([&](auto ic) {
@@ -1175,6 +1182,29 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   int mask = team_or16(bits);
   lbits = team_or16(lbits);
+  if (__popc(lbits) > MAX_LIMITS) {
+    // more joints at their limits than limit rows (K5 solves MAX_LIMITS): the smallest margins, i.e. the most violated, win
+    // (ties: lower joint, lower side) -- same rule as phase_detect, see there.  Lane t ranks its own joint's two sides against
+    // the team's margins in LDS.
+    if (valid && t < NQ) { C.limpen[2 * t] = st.q[t] + pp.qlim; C.limpen[2 * t + 1] = pp.qlim - st.q[t]; }
+    TEAM_SYNC();
+    int sel = 0;
+    if (valid && t < NQ) {
+      for (int side = 0; side < 2; side++) {
+        const int a = 2 * t + side;
+        if ((lbits >> a) & 1) {
+          const T pa = C.limpen[a];
+          int rank = 0;
+          for (int b = 0; b < 2 * NQ; b++) {
+            const T pb = C.limpen[b];
+            rank += (b != a && ((lbits >> b) & 1) && (pb < pa || (pb == pa && b < a))) ? 1 : 0;
+          }
+          if (rank < MAX_LIMITS) sel |= 1 << a;
+        }
+      }
+    }
+    lbits = team_or16(sel);
+  }
   if (pp.tm_on) sbits = team_or16(sbits);     // (uniform branch)
   if (__popc(mask) > MAX_CONTACTS) {
     // more than MAX_CONTACTS primitives touch (a robot lying on the ground -- the heaviest wavefronts, which set the launch
@@ -1198,7 +1228,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   const int nl = __popc(lbits);
   if (valid && t >= 4 && ((mask >> (t - 4)) & 1)) {    // base contacts: every touching point parks its own three rows
-    const int p = t - 4, nlt = nl > MAX_LIMITS ? MAX_LIMITS : nl, nc = __popc(mask);
+    const int p = t - 4, nlt = nl, nc = __popc(mask);
     const int cidx = __popc(mask & ((1 << p) - 1));
     const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
     const T lam0 = pp.warm * C.lamp[p];
@@ -1212,13 +1242,8 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   if (!lead) return;
   C.R0 = R0;
-  C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl > MAX_LIMITS ? MAX_LIMITS : nl; C.nlim = 0;
+  C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl; C.lsel = lbits;
   C.smask = sbits & mask;
-#pragma unroll
-  for (int L = 0; L < 4; L++) {
-    const int run = __popc(lbits & ((1 << (2 * NJ * L)) - 1));
-    C.limoff[L] = run > MAX_LIMITS ? MAX_LIMITS : run;
-  }
   // base link terms start the articulated-inertia accumulation
   constexpr solorl_link_data B = RB::MD.links[0];
   static_assert(B.com[0] == 0.0 && B.com[1] == 0.0 && B.com[2] == 0.0, "base COM at its origin");

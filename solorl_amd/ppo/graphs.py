@@ -23,6 +23,12 @@ from .fused import MiniBatchGrad, fused_ppo_loss, policy_act, policy_kernels_sup
 from .ppo import PPO
 
 
+def _kernels_enabled():
+    """SOLORL_PPO_KERNELS=0 keeps the rollout's act and the mini-batch step on their PyTorch paths (A/B runs)."""
+    import os
+    return os.environ.get("SOLORL_PPO_KERNELS", "1") != "0"
+
+
 def capture_kwargs():
     """With a process group up, its watchdog thread issues HIP calls of its own; a capture in the default "global" error mode
     would be invalidated by them.  Thread-local mode confines the capture's checks to the capturing thread."""
@@ -52,7 +58,7 @@ class GraphedRollout:
         # the arithmetic of train.rollout() with every result written where it is stored: the policy's outputs and the engine's
         # observations / rewards / done flags go straight into storage-side rows (the C ABI takes caller-owned pointers) -- two
         # launches per step (act, env step) instead of 35, and launches are what a step costs besides the env kernel
-        fused = policy_kernels_supported(self.ac)
+        fused = _kernels_enabled() and policy_kernels_supported(self.ac)
         if fused:                            # one launch for the whole of Policy.act (csrc/solorl_ppo.hip)
             self._pp = policy_params(self.ac)
         # the normal draws of all T steps and masks = 1 - done of all T steps are one launch each per rollout, not per step
@@ -98,7 +104,7 @@ class GraphedPPO(PPO):
                          l2_coef=l2_coef, max_grad_norm=max_grad_norm, use_clipped_value_loss=use_clipped_value_loss)
         self.fused_loss = fused_loss
         # hand-written mini-batch kernel (csrc/solorl_ppo.hip) where it is built for this policy's shape; otherwise autograd
-        self.fused_mlp = fused_mlp and policy_kernels_supported(actor_critic)
+        self.fused_mlp = fused_mlp and _kernels_enabled() and policy_kernels_supported(actor_critic)
         dev = next(actor_critic.parameters()).device
         # (fused: one multi-tensor launch per optimizer step instead of a dozen -- a captured mini-batch step is ~100 launches of a
         # few microseconds each, so launches are what it costs)

@@ -82,6 +82,22 @@ def test_joint_limit_row():
         assert np.abs(state_vec(o.get_state(0), 12) - state_vec(h, 12)).max() < 1e-10
 
 
+def test_joint_limit_selection_more_candidates_than_rows():
+    """Four joints inside their limit windows, two rows: the engine's phase_detect picks the same two (smallest margins) as the oracle."""
+    c = default_config(ROBOT_SOLO12, TASK_WALK)
+    rng = np.random.default_rng(1)
+    for trial in range(20):
+        o = Oracle(c, 1)
+        s = o.get_state(0); s.pos[2] = 5.0
+        for j in rng.choice(12, size=4, replace=False):
+            s.q[j] = float(rng.choice([-1, 1]) * (10.0 + rng.uniform(-0.45, 0.45)))
+            s.qd[j] = float(rng.uniform(-20, 20))
+        o.set_state(0, s); h = clone(s)
+        for _ in range(3):
+            o.substep(0); harness_py.substep(h, c, False)
+        assert np.abs(state_vec(o.get_state(0), 12) - state_vec(h, 12)).max() < 1e-9
+
+
 def test_standing_trajectory_fp32_within_1e3_rad():
     """The 1000-step trajectory-parity run (tests/golden: settled crouch start, PD hold, gentle
     sinusoidal references) through the kernel math in fp32 on the CPU: joint angles stay within the

@@ -171,3 +171,31 @@ def test_velocity_clamp():
             s.tau[j] = 3.0
         o.set_state(0, s); o.substep(0)
     assert np.abs(np.array(o.get_state(0).qd)).max() <= 100.0 + 1e-9
+
+
+def test_most_violated_joint_limits_are_the_ones_solved():
+    """K5 solves at most two joint-limit rows: when more joints sit at their limits, the two with the smallest margin (the most
+    violated) get them -- not the first two in joint order, which let a third joint run radians past its limit unopposed and
+    be thrown back at erp * violation / dt later (robots launched metres into the air under a random policy, round 2)."""
+    c = default_config(ROBOT_SOLO12, TASK_WALK)
+    o = Oracle(c, 1)
+    s = o.get_state(0); s.pos[2] = 5.0
+    s.q[0], s.q[1], s.q[7], s.q[10] = 9.8, 9.7, 10.4, -10.2            # margins 0.2, 0.3, -0.4, -0.2: joints 7 and 10 are violated
+    for j in (0, 1, 7, 10):
+        s.qd[j] = 0.0
+    o.set_state(0, s)
+    o.substep(0)
+    s1 = o.get_state(0)
+    # the violated joints are pushed back at erp * violation / dt = 0.2 * 0.4 * 240 and 0.2 * 0.2 * 240 rad/s ...
+    assert abs(s1.qd[7] + 0.2 * 0.4 * 240) < 0.5 and abs(s1.qd[10] - 0.2 * 0.2 * 240) < 0.5
+    # ... and the two that are merely near their limits (and not moving towards them) are left alone
+    assert abs(s1.qd[0]) < 2.0 and abs(s1.qd[1]) < 2.0
+    # nothing builds up over time: a random-torque run from this state keeps every joint within a fraction of a radian of its range
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        s2 = o.get_state(0)
+        for j in range(12):
+            s2.tau[j] = float(rng.uniform(-3, 3))
+        s2.pos[2] = 5.0; s2.lin_vel[2] = 0.0
+        o.set_state(0, s2); o.substep(0)
+        assert max(abs(v) for v in o.get_state(0).q[:12]) < 10.6

@@ -475,3 +475,31 @@ def test_urdf_inertia_vs_oracle(gpu_device, robot):
     for t in range(12):
         env0.step(torch.from_numpy((0.4 * rng.uniform(-1, 1, size=(32, n))).astype(np.float32)[:4]).cuda())
     assert np.abs(np.array(env0.get_state(0).q) - outs[PRECISION_F64]).max() > 1e-4      # the inertia model matters
+
+
+@pytest.mark.parametrize("robot", [ROBOT_SOLO8, ROBOT_SOLO12])
+def test_joint_limit_selection_vs_oracle(gpu_device, robot):
+    """More joints at their limits than limit rows (K5 solves two): the team-mode collision phase ranks the margins on the
+    team's lanes and must pick the oracle's two (smallest margin first).  States injected with 3-6 joints inside their limit
+    windows (some violated), standing on the ground so that contact slots sit behind the limit slots; one control step, fp64
+    engine to rounding, fp32 engine to the usual per-step bound."""
+    n = 8 if robot == ROBOT_SOLO8 else 12
+    for prec, tol in ((PRECISION_F64, 1e-9), (0, 2e-3)):
+        c = cfg_for(robot, TASK_WALK, precision=prec)
+        N = 64
+        env, orc = make(c, N, seed=5)
+        env.reset(); orc.reset()
+        rng = np.random.default_rng(7)
+        for i in range(N):
+            s = env.get_state(i)
+            for j in rng.choice(n, size=int(rng.integers(3, 7)), replace=False):
+                s.q[j] = float(rng.choice([-1, 1]) * (10.0 + rng.uniform(-0.45, 0.45)))
+                s.qd[j] = float(rng.uniform(-10, 10))
+            env.set_state(i, s)
+        resync(orc, env, N)
+        a = rng.uniform(-1, 1, size=(N, n)).astype(np.float32)
+        _, _, d, _ = env.step(torch.from_numpy(a).cuda()); _, _, od, _ = orc.step(a.astype(np.float64))
+        d = d.cpu().numpy()
+        errs = [np.abs(np.array(env.get_state(i).q)[:n] - np.array(orc.get_state(i).q)[:n]).max() for i in range(N) if not (d[i] or od[i])]
+        assert len(errs) > N // 2
+        assert np.median(errs) < tol and np.percentile(errs, 90) < 50 * tol, (prec, np.median(errs), np.percentile(errs, 90))

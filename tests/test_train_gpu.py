@@ -323,3 +323,25 @@ def test_hip_graph_update_with_the_minibatch_kernel_matches_eager(gpu_device):
         va = torch.cat([p.detach().flatten() for p in pol_a.parameters()])
         vb = torch.cat([p.detach().flatten() for p in pol_b.parameters()])
         assert ((va - vb).norm() / va.norm()).item() < 1e-3 and (va - vb).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("cfg,task,obs,act", [("basic.yaml", "walk", 60, 8), ("basic12.yaml", "pointgoal", 84, 12)])
+def test_ppo_train_loop_on_the_other_kernel_shapes(gpu_device, tmp_path, cfg, task, obs, act):
+    """The Solo8 (60 x 8) and Solo12 pointGoal (84 x 12) instantiations of the policy kernels inside the real loop
+    (configs/basic.yaml unmodified: treadmill on): finite parameters, finished episodes, sane losses."""
+    from solorl_amd.config import load_yaml
+    from solorl_amd.ppo.train import train
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = load_yaml(os.path.join(root, "configs", cfg))
+    config["task"] = task
+    args = types.SimpleNamespace(
+        num_agents=512, hidden_size=64, cuda=True, gamma=0.99, tau=0.95, clip_param=0.1, ppo_epoch=2, mini_batch_size=2048,
+        lr=2.5e-4, l2_coef=0.0, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5, use_linear_lr_decay=True,
+        use_gae=True, num_env_steps=512 * 64 * 2, seed=1, curriculum_schedule=0, log_interval=1, logdir=str(tmp_path),
+        base_checkpoint=None, save_interval=10, num_steps=64)
+    pol, hist = train(args, config)
+    assert pol.base.features[0].in_features == obs and pol.pi_dist.mean.out_features == act
+    assert len(hist) == 2 and all(torch.isfinite(p).all() for p in pol.parameters())
+    import math
+    # (value losses are large here by nature: a tumbling robot's walk reward 2 sign(vx) vx^2, baseEnv.py:115-119, reaches hundreds)
+    assert all(math.isfinite(h["value_loss"]) and h["value_loss"] >= 0 and abs(h["action_loss"]) < 10 and 0.5 < h["entropy"] < 3.0 for h in hist), hist
