@@ -193,7 +193,7 @@ int solorl_ppo_loss(const float* mean, const float* logstd, const float* values,
 
 /* Parameters of the reference's MLP actor-critic in PyTorch layout (nn.Linear weight = [out][in], row-major), device pointers:
  * base.critic.{0,2,4}, base.features.{0,2}, pi_dist.mean, pi_dist.logstd (agents/ppo/policy.py:62-81,138-148).  The kernels
- * are built for hidden = 64 and (obs_dim, act_dim) in {(76,12), (84,12), (60,8), (68,8)} -- one history level; other shapes
+ * are built for hidden = 64 and (obs_dim, act_dim) in {(38|42|76|84, 12), (30|34|60|68, 8)} -- zero or one history level; other shapes
  * return SOLORL_ERR_INVALID and the caller keeps its framework path. */
 typedef struct solorl_policy_params {
   int obs_dim, act_dim, hidden, reserved0;

@@ -111,9 +111,15 @@ template <int O, int NOUT, bool BACKWARD> struct NetRegs {
 #pragma unroll
       for (int q = 0; q < QO; ++q) {
         const int i0 = 8 * q + 4 * h;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i0 < O) v = *reinterpret_cast<const float4*>(w0 + (size_t)(32 * mt + c) * O + i0);       // (O % 4 == 0: a chunk is in or out)
-        a0[mt][q][0] = v.x; a0[mt][q][1] = v.y; a0[mt][q][2] = v.z; a0[mt][q][3] = v.w;
+        const float* wr = w0 + (size_t)(32 * mt + c) * O + i0;
+        if constexpr (O % 4 == 0) {                             // a 4-input chunk is wholly inside or outside the row
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i0 < O) v = *reinterpret_cast<const float4*>(wr);
+          a0[mt][q][0] = v.x; a0[mt][q][1] = v.y; a0[mt][q][2] = v.z; a0[mt][q][3] = v.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a0[mt][q][t] = i0 + t < O ? wr[t] : 0.f;
+        }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -162,9 +168,13 @@ __device__ __forceinline__ void mfma_forward(const NetRegs<O, NOUT, BW>& R, cons
 #pragma unroll
   for (int q = 0; q < QO; ++q) {
     const int i0 = 8 * q + 4 * h;
-    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i0 < O) xv = *reinterpret_cast<const float4*>(xrow + i0);
-    const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (O % 4 == 0) {
+      if (i0 < O) { const float4 xv = *reinterpret_cast<const float4*>(xrow + i0); x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) if (i0 + t < O) x[t] = xrow[i0 + t];
+    }
     if (i0 < O) store_x(i0, x);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -269,7 +279,7 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
         [&](int i0, const float (&x)[4]) {
           if (!ACTOR && on) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xt0[(size_t)(i0 + t) * m + row] = x[t];
+            for (int t = 0; t < 4; ++t) if (i0 + t < O) xt0[(size_t)(i0 + t) * m + row] = x[t];
           }
         },
         [&](int layer, f32x16 (&a)[2]) { store_units(layer == 1 ? xt1 : xt2, a); });
@@ -422,13 +432,14 @@ __global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Ar
   }
 }
 
+// observation widths of zero or one history level (14 + 2 n (+ 4 pointGoal), x 1 or x 2), action widths n = 8 / 12
 template <typename F> int dispatch_dims(int O, int A, F&& f) {
-  if (O == 76 && A == 12) return f(std::integral_constant<int, 76>(), std::integral_constant<int, 12>());
-  if (O == 84 && A == 12) return f(std::integral_constant<int, 84>(), std::integral_constant<int, 12>());
-  if (O == 60 && A == 8) return f(std::integral_constant<int, 60>(), std::integral_constant<int, 8>());
-  if (O == 68 && A == 8) return f(std::integral_constant<int, 68>(), std::integral_constant<int, 8>());
-  return solorl_fail_(SOLORL_ERR_INVALID, "policy kernels are built for the observation / action sizes of one history level "
-                                          "(76 or 84 x 12, 60 or 68 x 8); use the PyTorch path for other shapes");
+#define SOLO_DIMS(O_, A_) if (O == O_ && A == A_) return f(std::integral_constant<int, O_>(), std::integral_constant<int, A_>());
+  SOLO_DIMS(76, 12) SOLO_DIMS(84, 12) SOLO_DIMS(38, 12) SOLO_DIMS(42, 12)
+  SOLO_DIMS(60, 8) SOLO_DIMS(68, 8) SOLO_DIMS(30, 8) SOLO_DIMS(34, 8)
+#undef SOLO_DIMS
+  return solorl_fail_(SOLORL_ERR_INVALID, "policy kernels are built for the observation / action sizes of zero or one history level "
+                                          "(38, 42, 76 or 84 x 12; 30, 34, 60 or 68 x 8); use the PyTorch path for other shapes");
 }
 
 int check_policy(const solorl_policy_params* p, int device_id) {

@@ -54,11 +54,11 @@ def fused_ppo_loss(mean, logstd, values, action, old_logp, adv, vpred, ret, clip
 # Hand-written policy kernels (csrc/solorl_ppo.hip): the whole forward of Policy.act in one launch, and one PPO mini-batch's
 # gather + forward + losses + back-propagation in one launch (the weight gradients stay GEMMs).
 
-_SUPPORTED = {(76, 12), (84, 12), (60, 8), (68, 8)}
+_SUPPORTED = {(76, 12), (84, 12), (38, 12), (42, 12), (60, 8), (68, 8), (30, 8), (34, 8)}
 
 
 def policy_kernels_supported(actor_critic):
-    """The kernels are built for the reference's default MLP (hidden 64, agents/ppo/policy.py:62-81) on one history level."""
+    """The kernels are built for the reference's default MLP (hidden 64, agents/ppo/policy.py:62-81) on zero or one history level."""
     b = actor_critic.base
     try:
         o, h, a = b.features[0].in_features, b.features[0].out_features, actor_critic.pi_dist.mean.out_features

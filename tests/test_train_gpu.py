@@ -228,7 +228,7 @@ def _random_policy(dev, O=76, A=12, seed=0):
     return pol
 
 
-@pytest.mark.parametrize("O,A", [(76, 12), (84, 12), (60, 8), (68, 8)])
+@pytest.mark.parametrize("O,A", [(76, 12), (84, 12), (60, 8), (68, 8), (38, 12), (42, 12), (30, 8), (34, 8)])
 def test_policy_act_kernel_matches_torch(gpu_device, O, A):
     """solorl_policy_act (one launch) == Policy.act_into (agents/ppo/policy.py:33-49 arithmetic in torch), ragged row count,
     with noise and deterministic."""
@@ -249,7 +249,7 @@ def test_policy_act_kernel_matches_torch(gpu_device, O, A):
         assert torch.allclose(l0, l1, rtol=1e-4, atol=1e-4), (l0 - l1).abs().max().item()
 
 
-@pytest.mark.parametrize("O,A,clipped", [(76, 12, True), (84, 12, False), (60, 8, True)])
+@pytest.mark.parametrize("O,A,clipped", [(76, 12, True), (84, 12, False), (60, 8, True), (30, 8, True), (42, 12, False)])
 def test_minibatch_grad_kernel_matches_autograd(gpu_device, O, A, clipped):
     """MiniBatchGrad (solorl_ppo_grad_stage1 + row-sliced GEMMs) against loss.backward() of the reference's formulas
     (agents/ppo/ppo.py:46-74) on the same mini-batch: every parameter's gradient, and the three loss values."""
