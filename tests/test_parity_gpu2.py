@@ -503,3 +503,29 @@ def test_joint_limit_selection_vs_oracle(gpu_device, robot):
         errs = [np.abs(np.array(env.get_state(i).q)[:n] - np.array(orc.get_state(i).q)[:n]).max() for i in range(N) if not (d[i] or od[i])]
         assert len(errs) > N // 2
         assert np.median(errs) < tol and np.percentile(errs, 90) < 50 * tol, (prec, np.median(errs), np.percentile(errs, 90))
+
+
+@pytest.mark.parametrize("cfg_file", ["basic12.yaml", "basic.yaml"])
+def test_random_policy_keeps_robots_on_the_ground_full_size(gpu_device, cfg_file):
+    """Full-size physical-plausibility property (no oracle needed): under a Gaussian random policy, torque-limited 2.5 kg robots
+    neither fly nor exceed a few m/s.  Round 2 found 0.42 % of such steps with |reward| > 20 -- robots at z = 5-23 m and 50 m/s,
+    launched by a joint thrown back from radians past its limit (joint-limit rows) -- in engine and oracle
+    alike, which no engine-vs-oracle comparison can see."""
+    from solorl_amd.vec_env import SoloVecEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = load_yaml(os.path.join(root, "configs", cfg_file)); d["task"] = "walk"
+    c = config_from_dict(d)
+    N = 4096
+    env = SoloVecEnv(c, N, device="cuda:0", seed=1); env.reset()
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    vmax = torch.zeros((), device="cuda:0"); zmax = torch.zeros((), device="cuda:0"); rmax = torch.zeros((), device="cuda:0")
+    qmax = torch.zeros((), device="cuda:0")
+    n = env.act_dim
+    for t in range(500):
+        o, r, dn, _ = env.step_inplace(torch.randn(N, n, device="cuda:0", generator=g))
+        live = dn == 0
+        vmax = torch.maximum(vmax, (o[:, 4:7].norm(dim=1) * live).max()); zmax = torch.maximum(zmax, (o[:, 0] * live).max())
+        rmax = torch.maximum(rmax, (r.abs() * live).max()); qmax = torch.maximum(qmax, (o[:, 10:10 + n].abs() * live[:, None]).max() * 10.0)
+    env.close()
+    assert vmax.item() < 6.0 and zmax.item() < 0.6 and rmax.item() < 15.0, (vmax.item(), zmax.item(), rmax.item())
+    assert qmax.item() < 10.7, qmax.item()          # joints stay within a fraction of a radian of their +-10 rad range
