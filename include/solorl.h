@@ -21,6 +21,7 @@
  *                             evaluate_actions, the clipped losses, and autograd's back-propagation down to every layer's
  *                             pre-activation gradient (what `loss.backward()` computes before the weight-gradient GEMMs)
  *   solorl_ppo_grad_stage2 <- the weight-gradient products of that backward pass, written into the parameters' gradients
+ *   solorl_ppo_clip_adam   <- agents/ppo/ppo.py:75-77 (clip_grad_norm_ + optimizer.step) on the MLP's 13 parameter tensors
  *   solorl_get_state / solorl_set_state : no reference counterpart (parity-test hooks)
  *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
  *
@@ -243,6 +244,21 @@ int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage
                            void* stream);
 /* number of weight + bias elements of the actor-critic except logstd (one scratch chunk) */
 int solorl_ppo_grad_count(int obs_dim, int act_dim);
+
+/* Gradient-norm clip + Adam step over the 13 parameter tensors in one launch: nn.utils.clip_grad_norm_(max_grad_norm)
+ * (agents/ppo/ppo.py:75-76; coefficient max_norm / (norm + 1e-6) clamped to 1) followed by torch.optim.Adam's update (:32, :77:
+ * bias-corrected, eps outside the square root, L2 weight_decay added to the gradient, no amsgrad).  The parameters behind `p`
+ * are UPDATED IN PLACE; exp_avg / exp_avg_sq hold solorl_ppo_grad_count(obs_dim, act_dim) + act_dim floats in the order of
+ * solorl_policy_params' pointers; step [1] is incremented; lr [1] is read from the device (a schedule may rewrite it between
+ * calls); offset (optional) is advanced by offset_increment -- the mini-batch cursor of solorl_ppo_batch. */
+typedef struct solorl_adam_state {
+  float *exp_avg, *exp_avg_sq, *step;
+  const float* lr;
+  int64_t* offset;
+  int64_t offset_increment;
+  float beta1, beta2, eps, weight_decay, max_grad_norm /* <= 0: no clipping */, reserved0;
+} solorl_adam_state;
+int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* g, const solorl_adam_state* a, int device_id, void* stream);
 
 const char* solorl_last_error(void);
 const char* solorl_version(void);

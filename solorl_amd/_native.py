@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/solorl.h declares
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
            "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state",
-           "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_last_error", "solorl_version")
+           "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_ppo_clip_adam", "solorl_last_error", "solorl_version")
 
 
 class PolicyParams(C.Structure):            # solorl_policy_params
@@ -33,6 +33,12 @@ class PpoGrads(C.Structure):                # solorl_ppo_grads
     _fields_ = [(n, C.c_void_p) for n in ("critic_w0", "critic_b0", "critic_w1", "critic_b1", "critic_w2", "critic_b2", "actor_w0", "actor_b0",
                                           "actor_w1", "actor_b1", "mean_w", "mean_b", "logstd", "loss_sums", "logstd_sum", "scratch")] + [
         ("entropy_coef", C.c_float), ("reserved0", C.c_float)]
+
+
+class AdamState(C.Structure):               # solorl_adam_state
+    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step", C.c_void_p), ("lr", C.c_void_p), ("offset", C.c_void_p),
+                ("offset_increment", C.c_int64), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("max_grad_norm", C.c_float), ("reserved0", C.c_float)]
 
 
 class PpoStage1(C.Structure):               # solorl_ppo_stage1
@@ -70,6 +76,7 @@ def lib():
         L.solorl_ppo_grad_stage1.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoBatch), C.POINTER(PpoStage1), C.c_int, C.c_void_p]
         L.solorl_ppo_grad_stage2.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoStage1), C.c_int, C.POINTER(PpoGrads), C.c_int, C.c_void_p]
         L.solorl_ppo_grad_count.argtypes = [C.c_int, C.c_int]
+        L.solorl_ppo_clip_adam.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoGrads), C.POINTER(AdamState), C.c_int, C.c_void_p]
         for s in SYMBOLS:
             getattr(L, s)
         _LIB = L

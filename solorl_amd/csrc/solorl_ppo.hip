@@ -432,6 +432,52 @@ __global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Ar
   }
 }
 
+// ---------------------------------------------------------------- norm clip + Adam over all 13 parameter tensors, one workgroup
+// nn.utils.clip_grad_norm_ (agents/ppo/ppo.py:75-76) and torch.optim.Adam's update (:32, :77; no amsgrad) for ~20 k parameters are
+// nine small launches in PyTorch (norm, three scalar ops, scale, the multi-tensor Adam, the mini-batch cursor ...); here one
+// 1024-thread workgroup reads every gradient twice.
+struct AdamSeg { float* p; const float* g; int n, off; };
+struct AdamArgs { AdamSeg seg[13]; int total; float* m; float* v; float* step; const float* lr; float b1, b2, eps, wd, max_norm;
+                  long long* offset; long long inc; };
+__global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(const AdamArgs K) {
+  // (a variant with one flat element per (thread, slot) and all loads of a pass issued together was slower, 31 vs 22 us: finding
+  // an element's tensor means indexing the argument struct dynamically, which the compiler serves from scratch)
+  __shared__ float red[16];
+  __shared__ float coef_s;
+  const int tid = threadIdx.x;
+  float ss = 0.f;
+#pragma unroll 1
+  for (int s = 0; s < 13; ++s)
+    for (int i = tid; i < K.seg[s].n; i += 1024) { const float g = K.seg[s].g[i]; ss = fmaf(g, g, ss); }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    coef_s = K.max_norm > 0.f ? fminf(1.0f, K.max_norm / (sqrtf(t) + 1e-6f)) : 1.0f;      // clip_coef clamped to 1
+  }
+  __syncthreads();
+  const float coef = coef_s, step = *K.step + 1.0f, lr = *K.lr;
+  const float bc1 = 1.0f - powf(K.b1, step), bc2 = 1.0f - powf(K.b2, step);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+#pragma unroll 1
+  for (int s = 0; s < 13; ++s) {
+    const AdamSeg& S = K.seg[s];
+    for (int i = tid; i < S.n; i += 1024) {
+      float p = S.p[i], g = S.g[i] * coef;
+      if (K.wd != 0.f) g = fmaf(K.wd, p, g);
+      const int j = S.off + i;
+      const float m = K.m[j] + (1.0f - K.b1) * (g - K.m[j]);                 // exp_avg.lerp_(grad, 1 - beta1)
+      const float v = K.b2 * K.v[j] + (1.0f - K.b2) * g * g;
+      K.m[j] = m; K.v[j] = v;
+      S.p[i] = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + K.eps));
+    }
+  }
+  __syncthreads();                                                            // everyone has read *K.step
+  if (tid == 0) { *K.step = step; if (K.offset) *K.offset += K.inc; }
+}
+
 // observation widths of zero or one history level (14 + 2 n (+ 4 pointGoal), x 1 or x 2), action widths n = 8 / 12
 template <typename F> int dispatch_dims(int O, int A, F&& f) {
 #define SOLO_DIMS(O_, A_) if (O == O_ && A == A_) return f(std::integral_constant<int, O_>(), std::integral_constant<int, A_>());
@@ -521,6 +567,29 @@ int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage
   hipLaunchKernelGGL(ppo_grad_stage2_mfma_kernel, dim3(S.ntiles), dim3(64), 0, (hipStream_t)stream, S);
   hipLaunchKernelGGL(ppo_grad_stage3_kernel, dim3((S.total + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, T);
   return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage2/3 launch");
+}
+
+int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* g, const solorl_adam_state* a, int device_id, void* stream) {
+  if (int rc = check_policy(p, device_id)) return rc;
+  if (!g || !a || !a->exp_avg || !a->exp_avg_sq || !a->step || !a->lr) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_clip_adam: null argument");
+  const int O = p->obs_dim, A = p->act_dim;
+  const float* ps[13] = {p->critic_w0, p->critic_b0, p->critic_w1, p->critic_b1, p->critic_w2, p->critic_b2, p->actor_w0, p->actor_b0,
+                         p->actor_w1, p->actor_b1, p->mean_w, p->mean_b, p->logstd};
+  const float* gs[13] = {g->critic_w0, g->critic_b0, g->critic_w1, g->critic_b1, g->critic_w2, g->critic_b2, g->actor_w0, g->actor_b0,
+                         g->actor_w1, g->actor_b1, g->mean_w, g->mean_b, g->logstd};
+  const int ns[13] = {H * O, H, H * H, H, H, 1, H * O, H, H * H, H, A * H, A, A};
+  AdamArgs K;
+  int off = 0;
+  for (int i = 0; i < 13; ++i) {
+    if (!gs[i]) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_clip_adam: null gradient pointer");
+    K.seg[i] = {const_cast<float*>(ps[i]), gs[i], ns[i], off};
+    off += ns[i];
+  }
+  K.total = off; K.m = a->exp_avg; K.v = a->exp_avg_sq; K.step = a->step; K.lr = a->lr;
+  K.b1 = a->beta1; K.b2 = a->beta2; K.eps = a->eps; K.wd = a->weight_decay; K.max_norm = a->max_grad_norm;
+  K.offset = reinterpret_cast<long long*>(a->offset); K.inc = a->offset_increment;
+  hipLaunchKernelGGL(ppo_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, K);
+  return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_clip_adam_kernel launch");
 }
 
 }  // extern "C"

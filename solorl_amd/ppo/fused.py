@@ -170,3 +170,33 @@ class MiniBatchGrad:
 
     def reset(self):
         self.psum.zero_(); self.ent.zero_()
+
+
+class ClipAdam:
+    """clip_grad_norm_ + Adam (torch.optim.Adam's arithmetic, agents/ppo/ppo.py:32,75-77) for the MLP policy in ONE launch
+    (solorl_ppo_clip_adam) instead of nine; also advances the mini-batch cursor.  The learning rate is read from `lr`, a device
+    tensor (the linear schedule rewrites it between updates); moments and the step count live here."""
+
+    def __init__(self, mini_batch_grad, lr, max_grad_norm, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, offset=None, offset_increment=0):
+        mb = mini_batch_grad
+        dev = mb.psum.device
+        n = _native.lib().solorl_ppo_grad_count(mb.P.obs_dim, mb.P.act_dim) + mb.P.act_dim
+        assert n == sum(p.numel() for p in mb.ac.parameters())
+        self.P, self.G, self.dev = mb.P, mb.G, dev
+        self.exp_avg, self.exp_avg_sq = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.step = torch.zeros(1, device=dev)
+        assert torch.is_tensor(lr) and lr.is_cuda and lr.dtype == torch.float32
+        self.lr = lr
+        S = self.S = _native.AdamState()
+        S.exp_avg, S.exp_avg_sq, S.step, S.lr = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step.data_ptr(), lr.data_ptr()
+        S.offset, S.offset_increment = (offset.data_ptr() if offset is not None else 0), int(offset_increment)
+        S.beta1, S.beta2, S.eps, S.weight_decay = float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+        S.max_grad_norm = float(max_grad_norm) if max_grad_norm is not None else 0.0
+        self._offset = offset
+
+    def __call__(self):
+        with torch.cuda.device(self.dev):
+            _native.check(_native.lib().solorl_ppo_clip_adam(C.byref(self.P), C.byref(self.G), C.byref(self.S), self.dev.index or 0, _stream(self.dev)))
+
+    def zero_state(self):
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step.zero_()

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as D
-from .fused import MiniBatchGrad, fused_ppo_loss, policy_act, policy_kernels_supported, policy_params
+from .fused import ClipAdam, MiniBatchGrad, fused_ppo_loss, policy_act, policy_kernels_supported, policy_params
 from .ppo import PPO
 
 
@@ -132,10 +132,15 @@ class GraphedPPO(PPO):
             self._mb = MiniBatchGrad(self.actor_critic, storage, m, clip, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss,
                                      self._perm, self._off, self._adv)
 
+        self._ca = None
+        if self._mb is not None:             # norm clip + Adam + cursor in one launch; lr stays the optimizer's device tensor
+            g0 = self.optimizer.param_groups[0]
+            self._ca = ClipAdam(self._mb, g0["lr"], self.max_grad_norm, weight_decay=g0["weight_decay"], betas=g0["betas"], eps=g0["eps"],
+                                offset=self._off, offset_increment=m)
+
         def fwd_bwd():
             if self._mb is not None:     # three launches: gather + forward + losses + back-propagation; weight gradients; their sum
                 self._mb()
-                self._off += m
                 return
             idx = self._perm.index_select(0, self._ar + self._off)
             self._off += m
@@ -160,6 +165,9 @@ class GraphedPPO(PPO):
             self._stats += torch.stack([value_loss.detach(), action_loss.detach(), entropy.detach()])
 
         def opt_step():
+            if self._ca is not None:
+                self._ca()
+                return
             if self.max_grad_norm is not None:
                 # clip_grad_norm_ (agents/ppo/ppo.py:75-76) on the flat bucket every .grad is a view of: the 2-norm of the
                 # per-tensor norms is the norm of the concatenation
@@ -184,6 +192,8 @@ class GraphedPPO(PPO):
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.zero_()
+            if self._ca is not None:
+                self._ca.zero_state()
         self._stats.zero_(); self._off.zero_()
         if self._mb is not None:
             self._mb.reset()

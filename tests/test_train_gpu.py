@@ -345,3 +345,42 @@ def test_ppo_train_loop_on_the_other_kernel_shapes(gpu_device, tmp_path, cfg, ta
     import math
     # (value losses are large here by nature: a tumbling robot's walk reward 2 sign(vx) vx^2, baseEnv.py:115-119, reaches hundreds)
     assert all(math.isfinite(h["value_loss"]) and h["value_loss"] >= 0 and abs(h["action_loss"]) < 10 and 0.5 < h["entropy"] < 3.0 for h in hist), hist
+
+
+@pytest.mark.parametrize("wd,max_norm", [(0.0, 0.5), (1e-3, None)])
+def test_clip_adam_kernel_matches_torch(gpu_device, wd, max_norm):
+    """solorl_ppo_clip_adam (one launch) == nn.utils.clip_grad_norm_ + torch.optim.Adam.step (agents/ppo/ppo.py:32,75-77) over
+    five steps with fresh random gradients, a learning rate changed in between, weight decay, and the cursor advance."""
+    import copy
+    from solorl_amd.ppo import RolloutStorage
+    from solorl_amd.ppo import dist as D
+    from solorl_amd.ppo.fused import ClipAdam, MiniBatchGrad
+    dev = torch.device("cuda:0")
+    pol_a = _random_policy(dev, 76, 12, seed=9)
+    pol_b = copy.deepcopy(pol_a)
+    st = RolloutStorage(4, 64, (76,), 12, dev)
+    bucket = D.FlatGradBucket(pol_a.parameters())
+    off = torch.zeros((), dtype=torch.long, device=dev)
+    mb = MiniBatchGrad(pol_a, st, 64, 0.1, 0.5, 0.01, True, torch.arange(256, device=dev), off, torch.zeros(256, 1, device=dev))
+    lr = torch.tensor(1e-3, device=dev)
+    ca = ClipAdam(mb, lr, max_norm, weight_decay=wd, offset=off, offset_increment=64)
+    opt = torch.optim.Adam(pol_b.parameters(), lr=1e-3, weight_decay=wd)
+    g = torch.Generator(device=dev).manual_seed(1)
+    for it in range(5):
+        if it == 3:
+            lr.fill_(4e-4)
+            for grp in opt.param_groups:
+                grp["lr"] = 4e-4
+        flat = torch.randn(bucket.flat.shape, device=dev, generator=g) * (3.0 if it % 2 else 0.01)     # above and below the clip norm
+        bucket.flat.copy_(flat)
+        o = 0
+        for p in pol_b.parameters():
+            p.grad = flat[o:o + p.numel()].view_as(p).clone(); o += p.numel()
+        ca()
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(pol_b.parameters(), max_norm)
+        opt.step()
+        va = torch.cat([p.detach().flatten() for p in pol_a.parameters()])
+        vb = torch.cat([p.detach().flatten() for p in pol_b.parameters()])
+        assert torch.allclose(va, vb, rtol=1e-5, atol=2e-7), (it, (va - vb).abs().max().item())
+    assert off.item() == 5 * 64 and ca.step.item() == 5.0
