@@ -428,15 +428,19 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
   }
   int lsel = lcand;
   if (__popc(lcand) > MAX_LIMITS) {
-    lsel = 0;
+    // the two smallest margins in one ascending pass (strict comparisons: ties stay with the lower index)
+    static_assert(MAX_LIMITS == 2, "two-smallest scan");
+    T m1 = T(1e30), m2 = T(1e30);
+    int i1 = -1, i2 = -1;
 #pragma unroll
     for (int a = 0; a < 2 * NQ; a++) {
-      int rank = 0;
-#pragma unroll
-      for (int b = 0; b < 2 * NQ; b++)
-        if (b != a) rank += (((lcand >> b) & 1) && (lpen[b] < lpen[a] || (lpen[b] == lpen[a] && b < a))) ? 1 : 0;
-      if (((lcand >> a) & 1) && rank < MAX_LIMITS) lsel |= 1 << a;
+      if ((lcand >> a) & 1) {
+        const T pa = lpen[a];
+        if (pa < m1) { m2 = m1; i2 = i1; m1 = pa; i1 = a; }
+        else if (pa < m2) { m2 = pa; i2 = a; }
+      }
     }
+    lsel = (1 << i1) | (1 << i2);
   }
   C.mask = mask; C.nc = __popc(mask); C.nlim_total = __popc(lsel); C.lsel = lsel;
   C.smask = smask & mask;
@@ -1189,7 +1193,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     if (valid && t < NQ) { C.limpen[2 * t] = st.q[t] + pp.qlim; C.limpen[2 * t + 1] = pp.qlim - st.q[t]; }
     TEAM_SYNC();
     int sel = 0;
-    if (valid && t < NQ) {
+    if (valid && t < NQ) {             // (left to the compiler's unrolling: pinned to a rolled loop the step was 0.7 % slower)
       for (int side = 0; side < 2; side++) {
         const int a = 2 * t + side;
         if ((lbits >> a) & 1) {
