@@ -1,3 +1,5 @@
+"""Short PPO training on two configs, printing (value loss, action loss, entropy) per update -- run twice, with and without
+SOLORL_PPO_KERNELS=0, to compare the policy-kernel path with the PyTorch path end to end (dev tool)."""
 import os, sys, types, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from solorl_amd.config import load_yaml
