@@ -6,5 +6,5 @@ from solorl_amd.config import default_config, ROBOT_SOLO12, TASK_WALK
 from solorl_amd.vec_env import SoloVecEnv
 dev = torch.device("cuda:0")
 cfg = default_config(ROBOT_SOLO12, TASK_WALK); cfg.num_history_stack = 1
-env = SoloVecEnv(cfg, 4096, device=dev, seed=1); env.reset()
+env = SoloVecEnv(cfg, int(os.environ.get("PPO_N", "4096")), device=dev, seed=1); env.reset()
 print(bench.ppo_leg(env, dev, 1, int(os.environ.get("PPO_T", "400")), int(os.environ.get("PPO_EPOCHS", "1"))))
