@@ -81,7 +81,17 @@ def policy_params(actor_critic):
     for k, t in named.items():
         assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
         setattr(P, k, t.data_ptr())
+    P._tensors = named            # keeps the storages alive and lets check_params() notice a re-allocated parameter
     return P
+
+
+def check_params(P):
+    """The kernels read the parameters through raw pointers taken once: a parameter that was re-allocated since (module.to(),
+    load_state_dict(assign=True), p.data = ...) would be read from freed memory.  Host-side check, so it guards eager calls and
+    graph CAPTURES; a graph replayed after such a change cannot be guarded and must be rebuilt."""
+    for k, t in P._tensors.items():
+        if getattr(P, k) != t.data_ptr():
+            raise RuntimeError("policy parameter %s moved since solorl_policy_params was built; rebuild it (and any HIP graph)" % k)
 
 
 def _stream(dev):
@@ -91,6 +101,7 @@ def _stream(dev):
 def policy_act(params, obs, noise, value_out, action_out, logp_out):
     """Policy.act (agents/ppo/policy.py:33-49) in one launch: value_out [N,1], action_out [N,A] = mean + exp(logstd) * noise
     (noise [N,A] standard normal, or None for the deterministic action), logp_out [N,1]."""
+    check_params(params)
     n = obs.shape[0]
     dev = obs.device
     for t in (obs, value_out, action_out, logp_out) + (() if noise is None else (noise,)):
@@ -155,6 +166,7 @@ class MiniBatchGrad:
         G.loss_sums, G.logstd_sum, G.scratch, G.entropy_coef = self.psum.data_ptr(), self.ent.data_ptr(), self.scratch.data_ptr(), float(entropy_coef)
 
     def __call__(self):
+        check_params(self.P)
         dev = self.psum.device
         L = _native.lib()
         with torch.cuda.device(dev):

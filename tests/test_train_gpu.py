@@ -384,3 +384,18 @@ def test_clip_adam_kernel_matches_torch(gpu_device, wd, max_norm):
         vb = torch.cat([p.detach().flatten() for p in pol_b.parameters()])
         assert torch.allclose(va, vb, rtol=1e-5, atol=2e-7), (it, (va - vb).abs().max().item())
     assert off.item() == 5 * 64 and ca.step.item() == 5.0
+
+
+def test_policy_kernels_notice_a_reallocated_parameter(gpu_device):
+    """The kernels read parameters through raw pointers: a parameter re-allocated after solorl_policy_params was built is an
+    error at the next host-side call, not a read of freed memory."""
+    from solorl_amd.ppo.fused import policy_act, policy_params
+    dev = torch.device("cuda:0")
+    pol = _random_policy(dev, 76, 12)
+    P = policy_params(pol)
+    obs = torch.randn(64, 76, device=dev)
+    v, a, l = torch.empty(64, 1, device=dev), torch.empty(64, 12, device=dev), torch.empty(64, 1, device=dev)
+    policy_act(P, obs, None, v, a, l)
+    pol.pi_dist.logstd.data = pol.pi_dist.logstd.data.clone()
+    with pytest.raises(RuntimeError, match="moved"):
+        policy_act(P, obs, None, v, a, l)
