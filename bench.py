@@ -129,7 +129,7 @@ def ppo_leg(env, dev, world, T, epochs):
     N = env.nenvs
     torch.manual_seed(1)
     pol = Policy(env.observation_space.shape, env.action_space, None, {"hidden_size": 64}).to(dev)
-    mb = max(T * N // 50, 1)
+    mb = max((T * N // 50) // 64 * 64, 64)      # 50 mini-batches per epoch, rounded down to whole wavefronts (the policy kernels' granularity)
     agent = GraphedPPO(pol, 0.1, epochs, mb, 0.5, 0.01, lr=2.5e-4, max_grad_norm=0.5)
     st = RolloutStorage(T, N, env.observation_space.shape, env.act_dim, dev)
     st.obs[0].copy_(env.get_observation())
@@ -161,7 +161,7 @@ def ppo_leg(env, dev, world, T, epochs):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_roll, t_all = tt.tolist()
     out = {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
-           "ppo_epoch": epochs, "mini_batches_per_epoch": 50, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
+           "ppo_epoch": epochs, "mini_batches_per_epoch": (T * N) // mb, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
            "note": "policy act (solorl_policy_act) + env.step writing into the rollout storage per step, then GAE + PPO epochs (solorl_ppo_grad_stage1/2 + clip + Adam per mini-batch); rollout and mini-batch step replayed from HIP graphs"}
     if world > 1:                   # the collective of the data-parallel PPO step, timed on its own
         reps = 50
