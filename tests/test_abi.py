@@ -57,6 +57,30 @@ def test_error_convention(lib):
             SoloVecEnv(c, 4)
 
 
+def test_policy_kernel_entry_points_reject_bad_arguments(lib):
+    """The PPO-side entry points follow the same convention: negative code + message, never a crash -- null tables, a hidden size
+    or an observation width the kernels are not built for, and (without a GPU) no silent fallback."""
+    import torch
+    P = _native.PolicyParams()
+    assert lib.solorl_policy_act(None, None, None, 4, None, None, None, 0, None) == -1
+    assert b"null policy parameters" in lib.solorl_last_error()
+    P.obs_dim, P.act_dim, P.hidden = 76, 12, 32
+    assert lib.solorl_policy_act(C.byref(P), None, None, 4, None, None, None, 0, None) == -1
+    assert b"hidden size 64" in lib.solorl_last_error()
+    P.hidden = 64
+    assert lib.solorl_policy_act(C.byref(P), None, None, 4, None, None, None, 0, None) == -1          # null parameter pointers
+    assert b"null policy parameter pointer" in lib.solorl_last_error()
+    assert lib.solorl_ppo_grad_stage1(C.byref(P), None, None, 0, None) == -1
+    assert lib.solorl_ppo_grad_stage2(C.byref(P), None, 64, None, 0, None) == -1
+    assert lib.solorl_ppo_clip_adam(C.byref(P), None, None, 0, None) == -1
+    assert lib.solorl_ppo_grad_count(76, 12) == 2 * 64 * 77 + 2 * 64 * 65 + 65 + 12 * 65
+    if not torch.cuda.is_available():
+        for k, _t in P._fields_[4:]:
+            setattr(P, k, 4096)                       # non-null (never dereferenced on the host)
+        assert lib.solorl_policy_act(C.byref(P), None, None, 4, None, None, None, 0, None) == -2
+        assert b"no CPU fallback" in lib.solorl_last_error()
+
+
 def test_product_never_imports_oracle():
     for dp, _, fs in os.walk(os.path.join(ROOT, "solorl_amd")):
         for f in fs:
