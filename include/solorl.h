@@ -83,7 +83,10 @@ typedef struct solorl_config {
   double gravity;           /* simulation.py:19: 9.81 (pointing -z) */
   double erp;               /* contact/limit error-reduction (0.2, K7) */
   double linear_slop;       /* PyBullet solver linearSlop 1e-5 */
-  double warmstart;         /* warm-start factor on cached normal impulses (0.85) */
+  double warmstart;         /* warm-start factor on cached normal impulses.  Default 0: btMultiBodyConstraintSolver starts every
+                             * multibody contact row at zero impulse (its warm start is disabled in the source: "issues gaining
+                             * energy") [K].  btContactSolverInfo's 0.85 (rigid bodies) was the default of rounds 1-2; with it the
+                             * residual exit below destabilises a PD stance (measured) */
   double damping;           /* btMultiBody linear = angular damping 0.04 (K3) */
   double max_velocity;      /* generalized velocity clamp 100 (K5) */
   double joint_limit;       /* +-10 rad (URDF; solo.py:109) */
@@ -91,17 +94,17 @@ typedef struct solorl_config {
   /* Treadmill (simulation.py:45-77): a static 50 x 2 zero heightfield = a 49 m x 1 m strip at z = 0 centred on
    * y = +-treadmill_offset (sign redrawn at every reset, simulation.py:72-74), Bullet default friction 0.5; its
    * velocity is set on a mass-0 body and has no effect.  Modelled as: a contact whose point lies on the strip
-   * (|y - y_strip| <= treadmill_half_width) gets friction link_mu * treadmill_friction and is NOT reported by the
-   * feet sensor, which only queries the plane body (solo.py:313-317). */
+   * (|y - y_strip| <= treadmill_half_width) gets friction link_mu * treadmill_friction.  The feet sensor (solo.py:313-317
+   * queries the plane body) still reports such a foot: the infinite plane lies under the strip as well. */
   double treadmill_offset;      /* 0.49 (simulation.py:49) */
   double treadmill_half_width;  /* 0.5: (numHeightfieldColumns - 1) / 2 grid units */
   double treadmill_friction;    /* 0.5: Bullet's default lateral friction of the heightfield body */
-  /* PyBullet's solverResidualThreshold (1e-7 there): the PGS loop of a sub-step ends after the
-   * first iteration whose largest squared velocity-level change, max_rows (delta_impulse / jacDiagABInv)^2, is <= this
-   * value (or after solver_iterations).  Default 0 = always run solver_iterations sweeps: with this engine's stateless
-   * one-point-per-primitive contact set the threshold stops most solves after 3-10 sweeps, and a PD-held stance that is
-   * stable at 50 sweeps then is not -- whether PyBullet's persistent 4-point manifolds behave
-   * the same cannot be checked here, so the early exit is implemented (oracle and engine, parity-tested) but opt-in. */
+  /* PyBullet's solverResidualThreshold (1e-7, set by its physics server): the PGS loop of a sub-step
+   * ends after the first iteration whose largest squared velocity-level change, max_rows (delta_impulse / jacDiagABInv)^2, is
+   * <= this value (or after solver_iterations).  Default 1e-7 = the reference's setting (it never calls
+   * setPhysicsEngineParameter, simulation.py:13-35).  0 = always run solver_iterations sweeps (the default of rounds 1-2).
+   * Measured on the oracle: with warmstart = 0 the exit leaves a PD stance stable over 1000 control steps
+   * at a mean of ~12 sweeps; with warmstart = 0.85 it does not -- the pair (0, 1e-7) is what Bullet's multibody solver runs [K]. */
   double solver_residual_threshold;
 } solorl_config;
 
@@ -126,6 +129,10 @@ typedef struct solorl_info_soa {
    * info['episode_length'], 3 sum info['success'], 4..8 sums of the info['dr/...'] terms (stand, joint_pose, torque, balance,
    * progress), 9 episodes ended by the non-finite-state guard (not counted in 0..8). */
   float*   ep_stats;
+  /* [num_envs][act_dim], or NULL: the joint torques this step applied (solo.py:224-259 after the clip / the PD law of
+   * controllers/PD.py:3-10) -- what the reference hands to p.setJointMotorControlArray(TORQUE_CONTROL, forces=...).  Lets a
+   * test compare the engine's PD arithmetic with the reference's own PD() outputs (tests/golden/pd_golden.json). */
+  float*   applied_torque;
 } solorl_info_soa;
 #define SOLORL_EPSTAT_FIELDS 10
 
@@ -144,7 +151,7 @@ typedef struct solorl_env_state {
   double treadmill_y;                          /* centre line of the treadmill strip (+-treadmill_offset; 0 if unused) */
   int32_t timestep, need_reset;
   int32_t contact_mask;  /* bit p (0..23): primitive p was in contact in the last sub-step; bit 24+f: foot f's contact
-                          * was on the treadmill strip (hidden from the feet sensor) */
+                          * point was on the treadmill strip (strip friction; the feet sensor reports it all the same) */
   int32_t rng_counter;
 } solorl_env_state;
 
@@ -195,7 +202,9 @@ int solorl_ppo_loss(const float* mean, const float* logstd, const float* values,
 /* Parameters of the reference's MLP actor-critic in PyTorch layout (nn.Linear weight = [out][in], row-major), device pointers:
  * base.critic.{0,2,4}, base.features.{0,2}, pi_dist.mean, pi_dist.logstd (agents/ppo/policy.py:62-81,138-148).  The kernels
  * are built for hidden = 64 and (obs_dim, act_dim) in {(38|42|76|84, 12), (30|34|60|68, 8)} -- zero or one history level; other shapes
- * return SOLORL_ERR_INVALID and the caller keeps its framework path. */
+ * return SOLORL_ERR_INVALID and the caller keeps its framework path.  Alignment: the weight matrices critic_w1/w2, actor_w1,
+ * mean_w -- and, when obs_dim % 4 == 0, critic_w0, actor_w0 and every `obs` array handed to solorl_policy_act /
+ * solorl_ppo_batch -- are read as float4 rows and must start on a 16-byte boundary (checked: SOLORL_ERR_INVALID otherwise). */
 typedef struct solorl_policy_params {
   int obs_dim, act_dim, hidden, reserved0;
   const float *critic_w0, *critic_b0, *critic_w1, *critic_b1, *critic_w2, *critic_b2;

@@ -348,7 +348,7 @@ static void substep(oracle_env* E, int ei) {
   }
   int nnormal_end = nr;
   /* treadmill (reference simulation.py:45-77; model: include/solorl.h treadmill_*): a contact whose point lies on
-   * the strip takes the strip's friction (Bullet combines by product) and is hidden from the feet sensor */
+   * the strip takes the strip's friction (Bullet combines by product); the feet sensor still reports it (plane contact) */
   int on_strip[NP_MAX] = {0};
   if (C->use_treadmill)
     for (int a = 0; a < nact; a++) on_strip[act[a]] = fabs(P[act[a]][1] - s->treadmill_y) <= C->treadmill_half_width;
@@ -428,10 +428,12 @@ static void substep(oracle_env* E, int ei) {
 }
 
 /* ------------------------------------------------------------------ env logic */
-/* SoloBase.get_feet_ground_contact, solo.py:310-323: contact points between the foot link and `ground_id`, the PLANE
- * body -- a foot standing on the treadmill strip (its own body, simulation.py:59-64) is not reported (bit 24+f) */
+/* SoloBase.get_feet_ground_contact, solo.py:310-323: contact points between the foot link and `ground_id`, the PLANE body.
+ * The infinite plane also lies under the zero-height treadmill strip (simulation.py:23 loads it before the strip, :59-64),
+ * so a foot over the strip still has its plane contact and IS reported; bit 24+f of the mask only records that the
+ * foot's contact point lies on the strip (friction, see substep) -- it does not mask the sensor (round 2 did). */
 static int foot_contact(const oracle_env* E, const solorl_env_state* s, int f) {
-  return ((s->contact_mask >> E->md->foot_prim[f]) & 1) && !((s->contact_mask >> (24 + f)) & 1);
+  return (s->contact_mask >> E->md->foot_prim[f]) & 1;
 }
 
 /* SoloBase.get_current_state, reference solo.py:198-222 */

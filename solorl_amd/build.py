@@ -22,8 +22,30 @@ def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
+def _flags():
+    # -fno-slp-vectorize: packed fp32 operations appear only where the source writes 2-vectors (the PGS sweep, dynamics.hpp)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include")]
+    flags += ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
+    flags += os.environ.get("SOLORL_BUILD_FLAGS", "").split()                                 # dev experiments
+    return flags
+
+
+TAG = os.path.join(OBJ, "flags.txt")      # the flag string the objects (and the library) were built with
+
+
+def _same_flags():
+    return os.path.exists(TAG) and open(TAG).read() == " ".join(_flags())
+
+
 def needs_build():
-    return any(_stale(LIB, deps) for deps in UNITS.values())
+    """Stale sources OR a library built with other flags (an instrumented SOLORL_BUILD_DEFINES / SOLORL_BUILD_FLAGS build must
+    never be reused by a plain run: the bench and the tests would measure the wrong binary).  A missing flag record with a
+    library present (e.g. a prebuilt .so shipped to a box without its objects) counts as matching only for the plain flags."""
+    if any(_stale(LIB, deps) for deps in UNITS.values()):
+        return True
+    if os.path.exists(TAG):
+        return not _same_flags()
+    return bool(os.environ.get("SOLORL_BUILD_DEFINES", "").split() or os.environ.get("SOLORL_BUILD_FLAGS", "").split())
 
 
 def build(force=False, verbose=False):
@@ -31,12 +53,9 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-slp-vectorize: packed fp32 operations appear only where the source writes 2-vectors (the PGS sweep, dynamics.hpp)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include")]
-    flags += ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
-    flags += os.environ.get("SOLORL_BUILD_FLAGS", "").split()                                 # dev experiments
-    tag = os.path.join(OBJ, "flags.txt")                                                       # objects are only reused for the same flags
-    same = os.path.exists(tag) and open(tag).read() == " ".join(flags)
+    flags = _flags()
+    tag = TAG
+    same = _same_flags()
     objs = []
     for name, deps in UNITS.items():
         o = os.path.join(OBJ, name.replace(".hip", ".o"))

@@ -71,7 +71,7 @@ class InfoSoA(C.Structure):
     """ctypes mirror of ``solorl_info_soa`` (device pointers)."""
     _fields_ = [(k, C.c_void_p) for k in (
         "timeout", "success", "nan_reset", "episode_length", "episode_reward", "goals_reached",
-        "dr_stand", "dr_joint_pose", "dr_torque", "dr_balance", "dr_progress", "ep_stats")]
+        "dr_stand", "dr_joint_pose", "dr_torque", "dr_balance", "dr_progress", "ep_stats", "applied_torque")]
 
 
 EPSTAT_FIELDS = 10      # SOLORL_EPSTAT_FIELDS
@@ -89,10 +89,10 @@ def default_config(robot=ROBOT_SOLO12, task=TASK_WALK):
     c.settle_min, c.settle_max, c.disable_termination, c.precision = 5, 11, 0, PRECISION_F32
     c.kp, c.kd, c.max_torque = 5.0, 0.2, 3.0
     c.sim_dt, c.reward_dt, c.gravity = 1.0 / 240.0, 1.0 / 60.0, 9.81
-    c.erp, c.linear_slop, c.warmstart, c.damping = 0.2, 1e-5, 0.85, 0.04
+    c.erp, c.linear_slop, c.warmstart, c.damping = 0.2, 1e-5, 0.0, 0.04
     c.max_velocity, c.joint_limit, c.goal_radius = 100.0, 10.0, 2.0
     c.use_treadmill, c.treadmill_offset, c.treadmill_half_width, c.treadmill_friction = 0, 0.49, 0.5, 0.5
-    c.solver_residual_threshold = 0.0       # K7 early exit off: see include/solorl.h
+    c.solver_residual_threshold = 1e-7      # K7: PyBullet's solverResidualThreshold, see include/solorl.h
     return c
 
 

@@ -39,8 +39,18 @@ constexpr double DISC_EPS2 = 1e-12;
 // [1] the sub-steps, [2] last sub-step -> end, [3] whole kernel in s_memrealtime ticks (100 MHz), [4] sum over the sub-steps of
 // the slots the wave swept, [5] the maximum over the sub-steps of its largest contact count
 #if defined(SOLO_WAVE_TIMING) && !defined(SOLO_HOST_SHIM)
-constexpr int SOLO_WT_WAVES = 65536, SOLO_WT_FIELDS = 16;    // [6..15]: the ten intervals between the kernel's stamps
-__device__ unsigned long long solo_wave_times[SOLO_WT_WAVES][SOLO_WT_FIELDS];
+constexpr int SOLO_WT_WAVES = 65536, SOLO_WT_FIELDS = 28;    // [6..15]: the ten intervals between the kernel's stamps; [16..25]: per-phase
+__device__ unsigned long long solo_wave_times[SOLO_WT_WAVES][SOLO_WT_FIELDS];                                // sums over the sub-steps (SOLO_PT)
+// phase stamps of substep_team: after a full drain of the wave's memory counters (timing build only), lane 0 adds the ticks since
+// the previous stamp to phase slot i of the workgroup's LDS accumulators; step_team writes them out with its own stamps
+__shared__ unsigned long long solo_pt_acc[10];
+#define SOLO_PT_DECL() long long pt_last_ = 0
+#define SOLO_PT_BEGIN() do { __builtin_amdgcn_s_waitcnt(0); pt_last_ = clock64(); } while (0)
+#define SOLO_PT(i) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) { const long long n_ = clock64(); solo_pt_acc[i] += (unsigned long long)(n_ - pt_last_); } pt_last_ = clock64(); } while (0)
+#else
+#define SOLO_PT_DECL() do {} while (0)
+#define SOLO_PT_BEGIN() do {} while (0)
+#define SOLO_PT(i) do {} while (0)
 #endif
 
 template <int N, typename F, int... I>
@@ -1682,18 +1692,22 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   using TRW = TeamRows<T, LDS>;
   using CH = typename TeamCtx<T, ROBOT, LDS>::type;
   const CH ch{lds.lane};
+  SOLO_PT_DECL();
+  SOLO_PT_BEGIN();
   if (valid && t < Robot<ROBOT>::NQ) {   // sin/cos of joint t on lane t
     SubCtx<T, ROBOT>& C = ch.get();
     T sn, cs;
     sincos_t(C.ps.q[t], sn, cs);
     C.sn[t] = sn; C.cs[t] = cs;
   }
+  SOLO_PT(0);
   const bool ui = pp.urdf_inertia != 0;     // (uniform) K2: URDF tensors instead of the box rule
   if (ui) phase_front_team<T, ROBOT, LDS, CH, true>(ch, pp, lds, t, valid, lead);
   else phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
 #ifdef SOLO_DUP_FRONT      // dev: run an idempotent phase twice -- the launch-time delta is that phase's true cost
   phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
 #endif
+  SOLO_PT(1);
   if (valid && t < 4) {                                                                     // four legs on four lanes
     if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t);
     else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
@@ -1701,7 +1715,9 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
 #ifdef SOLO_DUP_LEGS
   if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
 #endif
+  SOLO_PT(2);
   if (valid) team_sum_base<T, ROBOT, CH>(ch, t);
+  SOLO_PT(3);
 #ifdef SOLO_DUP_BASE       // dev timing (tools/dev/dup_phase.sh); idempotent now that the leg sum is a separate step
   if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
 #endif
@@ -1709,13 +1725,18 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
   }
+  SOLO_PT(4);
   if (valid) phase_legrates_team<T, ROBOT, LDS, CH>(ch, pp, lds, t);
+  SOLO_PT(5);
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #ifdef SOLO_DUP_FINISH
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #endif
+  SOLO_PT(6);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.resid_thr >= T(0), pp.pgs_pipe != 0, lds, t);
+  SOLO_PT(7);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
+  SOLO_PT(8);
   return lead ? (ch.get().mask | strip_feet_bits(ch.get().smask)) : 0;
 }
 #endif  // !SOLO_HOST_SHIM

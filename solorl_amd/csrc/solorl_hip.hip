@@ -85,6 +85,7 @@ struct Outputs {
   float* obs; float* rew; unsigned char* done;
   unsigned char *timeout, *success, *nan_reset; int* ep_len; float *ep_rew, *goals, *dr0, *dr1, *dr2, *dr3, *dr4;
   float* ep_stats;     // [SOLORL_EPSTAT_FIELDS][N] finished-episode accumulators (include/solorl.h), or null
+  float* tau;          // [N][A] applied joint torques of this step (include/solorl.h applied_torque), or null
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -166,8 +167,8 @@ SD void current_state(const Env<T, Robot<ROBOT>::NQ>& E, int task, T (&cs)[DMAX]
 #pragma unroll
   for (int j = 0; j < NQ; j++) { cs[10 + j] = E.ps.q[j] * T(0.1); cs[10 + NQ + j] = E.ps.qd[j] * T(0.01); }   // (/10, /100: solo.py:208-209)
 #pragma unroll
-  for (int f = 0; f < 4; f++)    // solo.py:310-323: plane contacts only -- a foot on the treadmill strip (bit 24+f) is not reported
-    cs[10 + 2 * NQ + f] = (((E.mask >> (13 + 2 * f)) & 1) && !((E.mask >> (24 + f)) & 1)) ? T(1) : T(0);
+  for (int f = 0; f < 4; f++)    // solo.py:310-323: contacts with the plane body, which also lies under the treadmill strip -- a foot
+    cs[10 + 2 * NQ + f] = ((E.mask >> (13 + 2 * f)) & 1) ? T(1) : T(0);     // over the strip (bit 24+f) is reported like any other
   if (task == SOLORL_TASK_POINTGOAL) {
     cs[14 + 2 * NQ] = E.ps.pos.x * T(0.5); cs[15 + 2 * NQ] = E.ps.pos.y * T(0.5);
     cs[16 + 2 * NQ] = E.goal[0] * T(0.5); cs[17 + 2 * NQ] = E.goal[1] * T(0.5);
@@ -283,6 +284,7 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       tau[j] = clampv(t, T(P.max_torque));
     }
     if (mode != MODE_STEP) tau[j] = T(0);
+    if (out.tau && mode == MODE_STEP) out.tau[env * NQ + j] = (float)tau[j];
   }
 
   // ---- A4 simulator_step: history push (pre-step state), frame_skip sub-steps
@@ -443,6 +445,8 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   long long wts_[11];
   for (int i_ = 0; i_ < 11; i_++) wts_[i_] = 0;
   const long long wr0_ = wall_clock64();
+  if (threadIdx.x < 10) solo::solo_pt_acc[threadIdx.x] = 0;
+  __syncthreads();
   wts_[0] = clock64();
 #endif
   const int t = threadIdx.x & 15, col = threadIdx.x >> 4;
@@ -490,6 +494,7 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     if (P.control == SOLORL_CONTROL_TORQUE) tq = c * T(P.max_torque);
     else tq = clampv(T(P.kp) * (c * pp.qlim - C.ps.q[t]) - T(P.kd) * C.ps.qd[t], T(P.max_torque));
     C.tau_base[t] = mode == MODE_STEP ? tq : T(0);
+    if (out.tau && mode == MODE_STEP) out.tau[env * NQ + t] = (float)tq;
   }
   const T asq = team_sum16(a_t * a_t);        // sum of the raw, unclipped action squares (baseEnv.py:142-144)
   WT_STAMP(2);
@@ -716,6 +721,7 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     w_[0] = (unsigned long long)(wts_[3] - wts_[0]); w_[1] = (unsigned long long)(wts_[4] - wts_[3]); w_[2] = (unsigned long long)(wts_[10] - wts_[4]);
     w_[3] = (unsigned long long)(wall_clock64() - wr0_);
     for (int i_ = 0; i_ < 10; i_++) w_[6 + i_] = (unsigned long long)(wts_[i_ + 1] > wts_[i_] && wts_[i_] ? wts_[i_ + 1] - wts_[i_] : 0);
+    for (int i_ = 0; i_ < 10; i_++) w_[16 + i_] = solo::solo_pt_acc[i_];       // per-phase sums over the sub-steps (SOLO_PT)
   }
 #endif
 }
@@ -1131,10 +1137,10 @@ int solorl_default_config(solorl_config* c, int robot, int task) {
   c->frame_skip = 4; c->episode_length = 400; c->num_history_stack = 0;
   c->solver_iterations = 50; c->settle_min = 5; c->settle_max = 11; c->precision = SOLORL_PRECISION_F32;
   c->kp = 5.0; c->kd = 0.2; c->max_torque = 3.0; c->sim_dt = 1.0 / 240.0; c->reward_dt = 1.0 / 60.0; c->gravity = 9.81;
-  c->erp = 0.2; c->linear_slop = 1e-5; c->warmstart = 0.85; c->damping = 0.04; c->max_velocity = 100.0;
+  c->erp = 0.2; c->linear_slop = 1e-5; c->warmstart = 0.0; c->damping = 0.04; c->max_velocity = 100.0;
   c->joint_limit = 10.0; c->goal_radius = 2.0;
   c->use_treadmill = 0; c->treadmill_offset = 0.49; c->treadmill_half_width = 0.5; c->treadmill_friction = 0.5;
-  c->solver_residual_threshold = 0.0;
+  c->solver_residual_threshold = 1e-7;     // PyBullet's solverResidualThreshold (K7), see include/solorl.h
   return 0;
 }
 
@@ -1258,6 +1264,7 @@ int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* rewa
     o.timeout = info->timeout; o.success = info->success; o.nan_reset = info->nan_reset; o.ep_len = info->episode_length;
     o.ep_rew = info->episode_reward; o.goals = info->goals_reached; o.dr0 = info->dr_stand; o.dr1 = info->dr_joint_pose;
     o.dr2 = info->dr_torque; o.dr3 = info->dr_balance; o.dr4 = info->dr_progress; o.ep_stats = info->ep_stats;
+    o.tau = info->applied_torque;
   }
   if (h->sort) {   // re-sort the state by last contact count (stable), into the spare buffer
     hipStream_t st = (hipStream_t)stream;

@@ -16,6 +16,7 @@
 // profiles/r02_notes.md.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <type_traits>
 
 #include "../../include/solorl.h"
@@ -502,6 +503,10 @@ int check_policy(const solorl_policy_params* p, int device_id) {
   const void* ptrs[] = {p->critic_w0, p->critic_b0, p->critic_w1, p->critic_b1, p->critic_w2, p->critic_b2, p->actor_w0, p->actor_b0,
                         p->actor_w1, p->actor_b1, p->mean_w, p->mean_b, p->logstd};
   for (const void* q : ptrs) if (!q) return solorl_fail_(SOLORL_ERR_INVALID, "null policy parameter pointer");
+  // the kernels read weight rows as float4 (16 consecutive bytes per lane): every parameter tensor must start on a 16-byte
+  // boundary (torch allocations do; an offset view passed by another C-ABI caller would fault on the GPU instead)
+  const void* vec[] = {p->critic_w1, p->actor_w1, p->critic_w2, p->mean_w, p->obs_dim % 4 == 0 ? p->critic_w0 : nullptr, p->obs_dim % 4 == 0 ? p->actor_w0 : nullptr};
+  for (const void* q : vec) if (reinterpret_cast<uintptr_t>(q) & 15u) return solorl_fail_(SOLORL_ERR_INVALID, "policy weight matrices must be 16-byte aligned (rows are read as float4)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return solorl_fail_(SOLORL_ERR_NODEVICE, "no HIP device available (no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return solorl_fail_(SOLORL_ERR_NODEVICE, "device_id out of range");
@@ -517,6 +522,7 @@ int solorl_policy_act(const solorl_policy_params* p, const float* obs, const flo
                       float* logp_out, int device_id, void* stream) {
   if (int rc = check_policy(p, device_id)) return rc;
   if (!obs || !value_out || !action_out || !logp_out || n < 1) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_policy_act: null array or n < 1");
+  if (p->obs_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(obs) & 15u)) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_policy_act: obs must be 16-byte aligned (rows are read as float4)");
   const solorl_policy_params P = *p;
   return dispatch_dims(P.obs_dim, P.act_dim, [&](auto oc, auto ac) {
     constexpr int O = decltype(oc)::value, A = decltype(ac)::value;
@@ -534,6 +540,7 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
                         work->xt0, work->c_xt1, work->c_xt2, work->c_g1, work->c_g2, work->c_gh, work->a_xt1, work->a_xt2, work->a_g1,
                         work->a_g2, work->a_gh, work->partials};
   for (const void* q : ptrs) if (!q) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: null array");
+  if (p->obs_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(batch->obs) & 15u)) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: obs must be 16-byte aligned (rows are read as float4)");
   const solorl_policy_params P = *p;
   const solorl_ppo_batch B = *batch;
   const solorl_ppo_stage1 W = *work;

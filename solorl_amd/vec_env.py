@@ -117,7 +117,9 @@ class SoloVecEnv:
                       for k in _INFO_KEYS}
         # finished-episode accumulators [fields][N], updated by the step kernel itself (include/solorl.h ep_stats)
         self._ep_stats = torch.zeros((EPSTAT_FIELDS, N), dtype=torch.float32, **kw)
-        self._info_c = InfoSoA(ep_stats=self._ep_stats.data_ptr(), **{k: self._info[k].data_ptr() for k in _INFO_KEYS})
+        # the torques the step applied (include/solorl.h applied_torque): allocated on request only (record_applied_torque())
+        self._tau = None
+        self._info_c = InfoSoA(ep_stats=self._ep_stats.data_ptr(), applied_torque=None, **{k: self._info[k].data_ptr() for k in _INFO_KEYS})
         self.ob_rms = None          # VecNormalize(ob=False): agents/ppo/envs.py:26, read at train.py:126
         self.closed = False
 
@@ -201,6 +203,14 @@ class SoloVecEnv:
         for k in range(1, 9):
             out[EPSTAT_NAMES[k]] = (tot[k] / n) if n > 0 else float("nan")
         return out
+
+    def record_applied_torque(self):
+        """From now on every step also writes the joint torques it applied (after the clip / PD law, solo.py:224-259) into the
+        returned [N, A] tensor (overwritten by the next step)."""
+        if self._tau is None:
+            self._tau = torch.zeros((self.nenvs, self.act_dim), dtype=torch.float32, device=self.device)
+            self._info_c.applied_torque = self._tau.data_ptr()
+        return self._tau
 
     def increment_curriculum(self, value=1.0):
         _native.check(self.L.solorl_increment_curriculum(self._h, float(value)))

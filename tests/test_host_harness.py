@@ -127,15 +127,16 @@ def test_standing_trajectory_fp32_within_1e3_rad():
 def test_walk_torque_parity_input_divergence_horizon():
     """SURVEY.md 8(d) parity input verbatim (Solo12 walk, torque control, K = 8, a = 0.5 sin(2 pi t/60 + j pi/6), default
     torque lifetime, termination off).  1.5 N.m on a 2.5 kg robot folds it to the ground within 20 control steps and it
-    thrashes there: the fp64 oracle ITSELF, perturbed by 1e-12 rad, leaves the 1e-3 rad band after ~60 steps
-    (fixture `oracle_self_horizon`).  Divergence horizon = first step with max |dq| > 1e-3 rad vs the fixture:
+    thrashes there: the fp64 oracle ITSELF, perturbed by 1e-12 rad, leaves the 1e-3 rad band after 37 steps
+    (fixture `oracle_self_horizon`; ~60 with the fixed 50-sweep solve of rounds 1-2 -- the residual exit of K7 makes the
+    number of sweeps a discontinuous function of the state, which amplifies perturbations sooner).  Divergence horizon = first step with max |dq| > 1e-3 rad vs the fixture:
     the kernel math in fp64 holds as long as the oracle's own horizon, in fp32 (eps 6e-8 instead of 1e-12) 17 steps."""
     import os
     from tests.golden.make_golden import walk_cfg, walk_action, divergence_horizon
     from tests.util import GOLDEN
     g = np.load(os.path.join(GOLDEN, "walk_torque_traj.npz"))
     self_h = int(g["oracle_self_horizon"])
-    assert self_h == divergence_horizon(g["pert_dq"]) and 50 <= self_h <= 70          # (58 with the round-2 primitive set)
+    assert self_h == divergence_horizon(g["pert_dq"]) and 30 <= self_h <= 45          # measured 37 (K7 exit, no warm start); 58 with 50 fixed sweeps
     c = walk_cfg()
     o = Oracle(c, 1, seed=1); o.reset()
     h = {True: clone(o.get_state(0)), False: clone(o.get_state(0))}
@@ -159,13 +160,13 @@ def test_walk_torque_parity_input_divergence_horizon():
 
 @pytest.mark.parametrize("robot,n", [(ROBOT_SOLO8, 8), (ROBOT_SOLO12, 12)])
 def test_residual_threshold_early_exit_matches_oracle(robot, n):
-    """SURVEY Appendix B K7 / PyBullet's solverResidualThreshold (opt-in, include/solorl.h): the PGS loop of a sub-step
+    """SURVEY Appendix B K7 / PyBullet's solverResidualThreshold (the default since round 3, include/solorl.h): the PGS loop of a sub-step
     stops after the first sweep whose largest velocity-level change is within sqrt(1e-7) = 3.2e-4.  Same thrashing
     robot as test_contact_substeps_resynced: oracle and kernel math stop after the same sweep (errors stay at rounding),
     most solves stop long before 50 sweeps, and the truncated result is within a few thresholds of the full solve."""
-    c = default_config(robot, TASK_WALK); c.solver_residual_threshold = 1e-7
-    cfull = default_config(robot, TASK_WALK)
-    assert cfull.solver_residual_threshold == 0.0            # default: fixed 50 sweeps
+    c = default_config(robot, TASK_WALK)
+    assert c.solver_residual_threshold == 1e-7 and c.warmstart == 0.0     # defaults: PyBullet's exit, no multibody warm start
+    cfull = default_config(robot, TASK_WALK); cfull.solver_residual_threshold = 0.0          # fixed 50 sweeps
     rng = np.random.default_rng(1)
     o, ofull = Oracle(c, 1), Oracle(cfull, 1)
     e64, its, trunc = [], [], []
@@ -186,6 +187,6 @@ def test_residual_threshold_early_exit_matches_oracle(robot, n):
             trunc.append(np.abs(state_vec(a, n) - state_vec(ofull.get_state(0), n)).max())
         e64.append(np.abs(state_vec(a, n) - state_vec(h64, n)).max())
     e64, its, trunc = np.array(e64), np.array(its), np.array(trunc)
-    assert len(its) > 100 and np.median(its) <= 15 and its.max() <= 50 and (its < 50).mean() > 0.7
+    assert len(its) > 100 and np.median(its) <= 20 and its.max() <= 50 and (its < 50).mean() > 0.7     # measured medians 16 (Solo8) / 12 (Solo12)
     assert np.median(e64) < 1e-11 and np.percentile(e64, 95) < 1e-8           # same exit sweep in both implementations
     assert np.median(trunc) < 2e-3                                            # velocities within a few thresholds of the full solve

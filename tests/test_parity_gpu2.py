@@ -279,7 +279,7 @@ def test_curriculum_is_seen_by_a_replayed_graph(gpu_device):
 # ------------------------------------------------------------------------------------------------ treadmill
 def test_treadmill_configs_basic_yaml_vs_oracle(gpu_device):
     """configs/basic.yaml unmodified (Solo8 walk, use_treadmill: True): reset (strip side from the env's Philox stream,
-    snapshot per side), 40 resynced control steps, feet flags of the observation hidden on the strip."""
+    snapshot per side), 40 resynced control steps; feet over the strip are reported by the sensor (the plane lies under it)."""
     c = config_from_dict(load_yaml(os.path.join(ROOT, "configs", "basic.yaml")))
     assert c.use_treadmill == 1 and c.robot == ROBOT_SOLO8 and c.task == TASK_WALK
     N = 128
@@ -291,8 +291,9 @@ def test_treadmill_configs_basic_yaml_vs_oracle(gpu_device):
     for i in range(N):
         assert env.get_state(i).contact_mask == orc.get_state(i).contact_mask and env.get_state(i).rng_counter == orc.get_state(i).rng_counter == 2
     feet = og[:, 26:30]                                     # Solo8: 10 + 2*8 = 26 .. 29: FL FR HL HR
-    assert np.array_equal(feet[ys > 0], np.tile([0, 1, 0, 1], ((ys > 0).sum(), 1)))
-    assert np.array_equal(feet[ys < 0], np.tile([1, 0, 1, 0], ((ys < 0).sum(), 1)))
+    assert np.array_equal(feet, np.ones_like(feet))          # all four feet down and reported, strip or not
+    strip_bits = np.array([(env.get_state(i).contact_mask >> 24) & 0xF for i in range(N)])
+    assert np.array_equal(strip_bits[ys > 0], np.full((ys > 0).sum(), 0b0101)) and np.array_equal(strip_bits[ys < 0], np.full((ys < 0).sum(), 0b1010))
     rng = np.random.default_rng(3)
     dq, mism, strip_seen = [], 0, 0
     for t in range(40):

@@ -18,13 +18,16 @@ from solorl_amd.config import *
 from solorl_amd.vec_env import SoloVecEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 c = default_config(ROBOT_SOLO12, TASK_WALK); c.num_history_stack = 1
+if os.environ.get("WH_THR") is not None: c.solver_residual_threshold = float(os.environ["WH_THR"])
+if os.environ.get("WH_WARM") is not None: c.warmstart = float(os.environ["WH_WARM"])
+print("solver_residual_threshold %g, warmstart %g" % (c.solver_residual_threshold, c.warmstart))
 env = SoloVecEnv(c, N, device="cuda:0", seed=1); env.reset()
 g = torch.Generator(device="cuda:0"); g.manual_seed(1234)
 a = torch.rand(64, N, 12, device="cuda:0", generator=g) * 2 - 1
 for t in range(450): env.step_inplace(a[t % 64])
 L = _native.lib()
 nw = ((N + 3) // 4 + 7) & ~7
-F = 16
+F = 28
 recs, wall = [], []
 buf = (C.c_ulonglong * (nw * F))()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -51,6 +54,10 @@ print("intervals between stamps (us; mean over all wavefronts | over the slowest
 slow_ = tot >= np.percentile(tot, 99)
 for i, n_ in enumerate(segs):
     print("  %-28s %7.2f | %7.2f" % (n_, us(R[:, :, 6 + i].mean()), us(R[:, :, 6 + i][slow_].mean())))
+phases = ["sin/cos", "collision front", "legs (4 lanes)", "leg sum", "base solve (leader)", "leg rates", "row finish", "PGS sweep", "integrate"]
+print("phases of the sub-steps, summed over a step's %d sub-steps (us; mean over all wavefronts | over the slowest 1 %%; timing build drains the memory counters at every stamp):" % c.frame_skip)
+for i, n_ in enumerate(phases):
+    print("  %-28s %7.2f | %7.2f" % (n_, us(R[:, :, 16 + i].mean()), us(R[:, :, 16 + i][slow_].mean())))
 bw = 10.0
 edges = np.arange(0, us(tot.max()) + bw, bw)
 h, _ = np.histogram(us(tot), bins=edges)
@@ -61,7 +68,7 @@ for lo, n_ in zip(edges[:-1], h):
 # least squares: sub-step time of a wavefront = a + b * (slots swept, summed over its sub-steps)
 X = np.stack([np.ones(tot.size), R[:, :, 4].ravel()], axis=1)
 coef, *_ = np.linalg.lstsq(X, us(R[:, :, 1].ravel()), rcond=None)
-print("sub-steps of a wavefront = %.1f us + %.2f us per swept slot (50 sweeps each) => %.1f ns = %.0f cycles at 2.4 GHz per slot and sweep; "
+print("sub-steps of a wavefront = %.1f us + %.2f us per swept slot (x 50 if every solve ran 50 sweeps) => %.1f ns = %.0f cycles at 2.4 GHz per slot and sweep; "
       "mean slots per sub-step %.2f" % (coef[0], coef[1], coef[1] * 1e3 / 50, coef[1] * 1e3 / 50 * 2.4, R[:, :, 4].mean() / c.frame_skip))
 print("by the wavefront's largest contact count in the step (max over its sub-steps): share, mean duration (before / sub-steps / after)")
 for k in range(9):

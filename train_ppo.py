@@ -61,16 +61,20 @@ def main(argv=None):
     if args.num_steps is None:
         args.num_steps = config["episode_length"]
     writer = None
+    rank = int(os.environ.get("RANK", "0"))
     if args.logdir is not None:      # run directory named as training/train_ppo.py:64-72
         from datetime import datetime
+        # under torch.distributed.run every rank runs main(): the stamp comes from the launcher's start time when it exports one
+        # (TORCHELASTIC_RUN_ID does not carry it), else from this rank's clock -- only rank 0's directory is ever written to
         stamp = datetime.now().strftime("%Y%m%d-%H%M%S") if args.timestamp is None else datetime.now().strftime("%Y%m%d-") + args.timestamp
         task = args.task + "_" if args.task is not None else ""
         args.logdir = os.path.join(args.logdir, "Solo" + args.env_name.capitalize() + "_" + task + stamp)
-        try:                         # tensorboard is optional here (not installed in the build image)
-            from torch.utils.tensorboard import SummaryWriter
-            writer = SummaryWriter(args.logdir)
-        except Exception:
-            writer = None
+        if rank == 0:                # the reference is single-process; with N ranks only rank 0 logs and saves
+            try:                     # tensorboard is optional here (not installed in the build image)
+                from torch.utils.tensorboard import SummaryWriter
+                writer = SummaryWriter(args.logdir)
+            except Exception:
+                writer = None
     return train(args, config, None, writer)
 
 
