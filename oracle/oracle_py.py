@@ -19,7 +19,7 @@ def build(force=False):
     so = os.path.join(_HERE, "build", "liboracle.so")
     if force or not os.path.exists(so) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
-            for f in ("solo_oracle.c", "solo_oracle.h", "../include/solorl.h", "../include/solorl_model_data.h")):
+            for f in ("solo_oracle.c", "solo_oracle.h", "hull_data.h", "../include/solorl.h", "../include/solorl_model_data.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "build/liboracle.so"],
                               stdout=subprocess.DEVNULL)
     return so
@@ -34,7 +34,8 @@ def lib():
         for name in ("oracle_destroy", "oracle_dims", "oracle_reset", "oracle_step", "oracle_get_observation",
                      "oracle_increment_curriculum", "oracle_get_state", "oracle_set_state", "oracle_set_threads",
                      "oracle_substep", "oracle_mass_matrix", "oracle_forward_dynamics", "oracle_energy_momentum",
-                     "oracle_prim_points", "oracle_last_lambda", "oracle_philox", "oracle_euler_from_quat"):
+                     "oracle_prim_points", "oracle_last_lambda", "oracle_philox", "oracle_euler_from_quat", "oracle_set_caps",
+                     "oracle_set_contact_model", "oracle_last_counts"):
             getattr(L, name).restype = None
         L.oracle_increment_curriculum.argtypes = [C.c_void_p, C.c_double]
         L.oracle_last_iterations.restype = C.c_int
@@ -123,6 +124,20 @@ class Oracle:
 
     def last_iterations(self, i=0):
         return int(self.L.oracle_last_iterations(self.h, int(i)))
+
+    def set_caps(self, max_contacts=0, max_limits=0):
+        """engine emulation (0 = uncapped, the default): see oracle_set_caps"""
+        self.L.oracle_set_caps(self.h, int(max_contacts), int(max_limits))
+
+    def set_contact_model(self, model):
+        """0 = analytic primitives (the engine's model), 1 = hull manifolds (Bullet's scheme [K6])"""
+        self.L.oracle_set_contact_model(self.h, int(model))
+
+    def last_counts(self, i=0):
+        """(contact points found, solved, joint-limit candidates, solved) of env i's last sub-step"""
+        o = (C.c_int * 4)()
+        self.L.oracle_last_counts(self.h, int(i), o)
+        return tuple(o)
 
     def last_lambda(self, i=0):
         o = np.zeros(self.np)

@@ -15,6 +15,7 @@
  */
 #include "solo_oracle.h"
 #include "../include/solorl_model_data.h"
+#include "hull_data.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -23,10 +24,16 @@
 #define NL_MAX SOLORL_MAX_LINKS
 #define NV_MAX (6 + SOLORL_MAX_DOF)
 #define NP_MAX SOLORL_MAX_PRIMS
-#define MAX_CONTACTS 8    /* engine-wide cap on simultaneously solved contact points */
-#define MAX_LIMITS 2      /* cap on simultaneously solved joint-limit rows */
-#define MAX_ROWS (MAX_LIMITS + 3 * MAX_CONTACTS)
-#define LIMIT_WINDOW 0.5  /* a limit row exists when the joint is within 0.5 rad of +-joint_limit */
+/* No caps of its own: every joint within LIMIT_WINDOW of a limit gets its row and every contact point its three rows,
+ * as in Bullet.  The HIP engine solves at most 8 contact points and 2 limit rows per robot (its PGS slot count); oracle_set_caps()
+ * lets a test impose those numbers here to measure what they cost (tests/test_oracle_caps.py) -- the parity tests run uncapped. */
+#define NPT_MAX (4 * NL_MAX)                       /* contact points: <= 4 per link in the manifold model, NP_MAX primitives otherwise */
+#define MAX_ROWS (2 * SOLORL_MAX_DOF + 3 * NPT_MAX)
+#define HULL_MARGIN 0.001 /* collision margin of URDF-imported convex hulls */
+/* A joint-limit row exists while the joint is AT or BEYOND its limit (margin <= 0): btMultiBodyJointLimitConstraint::createConstraintRows
+ * skips a row whose `penetration > 0` [K5].  (Rounds 1-2: a speculative row from 0.5 rad before the limit; ORACLE_LIMIT_WINDOW=0.5
+ * restores it for the measurement in tests/test_oracle_caps.py.) */
+static double LIMIT_WINDOW = 0.0;
 #define DISC_EPS2 1e-12
 
 /* ------------------------------------------------------------------ small algebra */
@@ -110,7 +117,17 @@ struct oracle_env {
   solorl_env_state* st;
   double (*last_lambda)[NP_MAX];
   int* last_iterations;          /* PGS iterations the last sub-step of each env ran (early exit, K7) */
+  int* last_counts;              /* [N][4]: last sub-step's contact points before / after the cap, limit candidates before / after */
+  int cap_contacts, cap_limits;  /* 0 = none (default); oracle_set_caps */
+  /* contact model: 0 = the analytic primitives the HIP engine uses (one stateless support point per primitive);
+   * 1 = Bullet's own scheme [K6]: per link the convex hull of its collision mesh against the plane, ONE new point per step (the
+   * support vertex) into a persistent manifold of <= 4 points, refreshed / dropped by the breaking threshold */
+  int contact_model;
+  unsigned manifold_links;      /* model 1: bit l = link l collides through its hull manifold; links not in the mask keep their primitives (ablation hook) */
+  const oracle_hull* hulls;
+  struct manifold_t* man;        /* [N][NL_MAX], model 1 */
 };
+typedef struct manifold_t { int n; double local[4][3], worldB[4][3], dist[4], lam[4]; } manifold_t;
 static const solorl_prim_data* prim_of(const oracle_env* E, int p) { return &E->md->prims[p]; }
 
 typedef struct {
@@ -265,6 +282,105 @@ static double prim_point(const oracle_env* E, const kin_t* K, int p, double* P) 
   return P[2];
 }
 
+/* one contact point of a sub-step: link, world point, signed distance to the plane, friction, warm-start impulse, id (primitive
+ * index, or 4 * link + manifold slot) */
+typedef struct { int link, id, prim; double P[3], dist, friction, lam0; } cpoint_t;   /* prim: 1 = id is a primitive index */
+
+static int collide_primitives(const oracle_env* E, const solorl_env_state* s, const kin_t* K, cpoint_t* cp, unsigned skip_links) {
+  int n = 0;
+  for (int p = 0; p < E->np; p++) {
+    double P[3];
+    if ((skip_links >> prim_of(E, p)->link) & 1u) continue;
+    const double d = prim_point(E, K, p, P);
+    if (d < prim_of(E, p)->margin) {
+      cpoint_t* c = &cp[n++];
+      c->link = prim_of(E, p)->link; c->id = p; c->prim = 1; v3cpy(c->P, P); c->dist = d; c->friction = prim_of(E, p)->friction; c->lam0 = s->lambda_prev[p];
+    }
+  }
+  return n;
+}
+
+/* Bullet's convex-vs-plane path [K6], per link: btConvexPlaneCollisionAlgorithm::processCollision adds ONE point -- the hull's
+ * support vertex towards the plane (margin included) when closer than the manifold's breaking threshold -- through
+ * btManifoldResult::addContactPoint (nearest cached point within the threshold is replaced, else appended, a full cache of 4
+ * replaces the entry that keeps the deepest point and the largest area: btPersistentManifold::sortCachedPoints), then
+ * refreshContactPoints() recomputes every cached point's distance from its link-local point and drops those whose distance or
+ * tangential drift exceeds the threshold.  Threshold = the link's relative breaking threshold (model table `margin`). */
+static int collide_manifolds(oracle_env* E, int ei, const kin_t* K, cpoint_t* cp) {
+  int n = 0;
+  for (int l = 0; l < E->nl; l++) {
+    if (!((E->manifold_links >> l) & 1u)) continue;
+    manifold_t* m = &E->man[(size_t)ei * NL_MAX + l];
+    const oracle_hull* H = &E->hulls[l];
+    double thr = 0, fric = 0.5;
+    int have = 0;
+    for (int p = 0; p < E->np; p++) if (prim_of(E, p)->link == l) { thr = prim_of(E, p)->margin; fric = prim_of(E, p)->friction; have = 1; break; }
+    if (!have) {   /* links without a primitive (lower legs): threshold from the hull's own bounding sphere about the COM */
+      double lo[3] = {1e9, 1e9, 1e9}, hi[3] = {-1e9, -1e9, -1e9}, c[3], hx[3];
+      for (int i = 0; i < H->n; i++) for (int k = 0; k < 3; k++) { if (H->v[i][k] < lo[k]) lo[k] = H->v[i][k]; if (H->v[i][k] > hi[k]) hi[k] = H->v[i][k]; }
+      for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]) - E->md->links[l].com[k]; hx[k] = 0.5 * (hi[k] - lo[k]) + HULL_MARGIN; }
+      thr = 0.02 * (v3norm(c) + v3norm(hx)); fric = 1.0;   /* URDF <contact> friction of the lower legs is 1.0 */
+    }
+    /* support vertex: lowest hull vertex in the world (plane normal +z) */
+    const double* R = K->R[l];
+    int best = 0; double zb = 1e30;
+    for (int i = 0; i < H->n; i++) {
+      const double z = R[6] * H->v[i][0] + R[7] * H->v[i][1] + R[8] * H->v[i][2];
+      if (z < zb) { zb = z; best = i; }
+    }
+    const double dist = zb + K->o[l][2] - HULL_MARGIN;
+    if (dist < thr) {
+      /* localA = link-frame coordinates of (vertex - margin * normal): what btManifoldResult stores as m_localPointA */
+      double down[3] = {0, 0, -HULL_MARGIN}, dl[3], loc[3], wA[3];
+      m3tmulv(dl, R, down);
+      for (int k = 0; k < 3; k++) loc[k] = H->v[best][k] + dl[k];
+      m3mulv(wA, R, loc); v3add(wA, wA, K->o[l]);
+      int slot = -1; double shortest = thr * thr;
+      for (int i = 0; i < m->n; i++) {            /* getCacheEntry */
+        double d[3]; v3sub(d, m->local[i], loc);
+        const double dd = v3dot(d, d);
+        if (dd < shortest) { shortest = dd; slot = i; }
+      }
+      int fresh = 0;
+      if (slot < 0) {
+        fresh = 1;
+        if (m->n < 4) slot = m->n++;
+        else {                                    /* sortCachedPoints: keep the deepest, maximise the area (gContactCalcArea3Points) */
+          int deep = -1; double maxpen = dist;
+          for (int i = 0; i < 4; i++) if (m->dist[i] < maxpen) { deep = i; maxpen = m->dist[i]; }
+          double res[4] = {0, 0, 0, 0}, a[3], b[3], c[3];
+          if (deep != 0) { v3sub(a, loc, m->local[1]); v3sub(b, m->local[3], m->local[2]); v3cross(c, a, b); res[0] = v3dot(c, c); }
+          if (deep != 1) { v3sub(a, loc, m->local[0]); v3sub(b, m->local[3], m->local[2]); v3cross(c, a, b); res[1] = v3dot(c, c); }
+          if (deep != 2) { v3sub(a, loc, m->local[0]); v3sub(b, m->local[3], m->local[1]); v3cross(c, a, b); res[2] = v3dot(c, c); }
+          if (deep != 3) { v3sub(a, loc, m->local[0]); v3sub(b, m->local[2], m->local[1]); v3cross(c, a, b); res[3] = v3dot(c, c); }
+          slot = 0;
+          for (int i = 1; i < 4; i++) if (res[i] > res[slot]) slot = i;
+        }
+      }
+      v3cpy(m->local[slot], loc);
+      m->worldB[slot][0] = wA[0]; m->worldB[slot][1] = wA[1]; m->worldB[slot][2] = 0;   /* the vertex projected on the plane */
+      m->dist[slot] = dist;
+      if (fresh) m->lam[slot] = 0;                /* replaceContactPoint keeps the cached impulse, a new point starts at 0 */
+    }
+    for (int i = m->n - 1; i >= 0; i--) {         /* refreshContactPoints */
+      double wA[3];
+      m3mulv(wA, R, m->local[i]); v3add(wA, wA, K->o[l]);
+      m->dist[i] = wA[2];
+      const double dx = m->worldB[i][0] - wA[0], dy = m->worldB[i][1] - wA[1];
+      if (m->dist[i] > thr || dx * dx + dy * dy > thr * thr) {   /* removeContactPoint: the last entry takes its place */
+        const int last = --m->n;
+        if (i != last) { v3cpy(m->local[i], m->local[last]); v3cpy(m->worldB[i], m->worldB[last]); m->dist[i] = m->dist[last]; m->lam[i] = m->lam[last]; }
+      }
+    }
+    for (int i = 0; i < m->n; i++) {
+      cpoint_t* c = &cp[n++];
+      c->link = l; c->id = 4 * l + i; c->prim = 0; c->dist = m->dist[i]; c->friction = fric; c->lam0 = m->lam[i];
+      m3mulv(c->P, R, m->local[i]); v3add(c->P, c->P, K->o[l]);
+    }
+  }
+  return n;
+}
+
 typedef struct { double J[NV_MAX], B[NV_MAX], rhs, dinv, lam, mu; int parent; /* -1: lo=0,hi=inf */ } row_t;
 
 static void clampv(double* v, double lim) { if (*v > lim) *v = lim; if (*v < -lim) *v = -lim; }
@@ -277,24 +393,48 @@ static void substep(oracle_env* E, int ei) {
   kin_t K;
   kinematics(E, s, &K);
 
-  /* --- collision detection at the start-of-step pose (K1, K6') */
-  int act[NP_MAX], nact = 0; double P[NP_MAX][3], dist[NP_MAX];
-  for (int p = 0; p < E->np; p++) {
-    dist[p] = prim_point(E, &K, p, P[p]);
-    if (dist[p] < prim_of(E, p)->margin) act[nact++] = p;
+  /* K5: every candidate (joint at or beyond a limit) gets its row, in joint order.  With oracle_set_caps (engine emulation)
+   * only the cap_limits candidates with the SMALLEST margin, i.e. the most violated first (ties: lower joint, lower side) -- the
+   * engine's rule since round 2 (the first two in joint order let a third joint run radians past its limit and be thrown back). */
+  row_t rows[MAX_ROWS]; int nr = 0;
+  int lim_sel[2 * SOLORL_MAX_DOF]; memset(lim_sel, 0, sizeof lim_sel);
+  {
+    double pens[2 * SOLORL_MAX_DOF]; int cand[2 * SOLORL_MAX_DOF], ncand = 0, nsel = 0;
+    for (int j = 0; j < n; j++)
+      for (int side = 0; side < 2; side++) {
+        pens[2 * j + side] = side == 0 ? s->q[j] + C->joint_limit : C->joint_limit - s->q[j];
+        if (pens[2 * j + side] <= LIMIT_WINDOW) cand[ncand++] = 2 * j + side;
+      }
+    for (int a = 0; a < ncand; a++) {
+      int rank = 0;
+      for (int b2 = 0; b2 < ncand; b2++)
+        rank += pens[cand[b2]] < pens[cand[a]] || (pens[cand[b2]] == pens[cand[a]] && cand[b2] < cand[a]);
+      lim_sel[cand[a]] = E->cap_limits <= 0 || rank < E->cap_limits;
+      nsel += lim_sel[cand[a]];
+    }
+    E->last_counts[4 * ei + 2] = ncand; E->last_counts[4 * ei + 3] = nsel;
   }
-  if (nact > MAX_CONTACTS) { /* keep the MAX_CONTACTS deepest (ties: lower primitive id) */
-    int keep[NP_MAX] = {0};
+  const int nsel_limits = E->last_counts[4 * ei + 3];
+  /* --- collision detection at the start-of-step pose (K1, K6): the list of contact points */
+  cpoint_t cp[NPT_MAX]; int nact = 0;
+  if (E->contact_model == 0) nact = collide_primitives(E, s, &K, cp, 0u);
+  else { nact = collide_manifolds(E, ei, &K, cp); nact += collide_primitives(E, s, &K, cp + nact, E->manifold_links); }
+  E->last_counts[4 * ei + 0] = nact;
+  /* engine emulation (oracle_set_caps): the engine's limit rows 3 and 4 take the place of contact points (dynamics.hpp MAX_LIMITS) */
+  const int capc = E->cap_contacts - (nsel_limits > 2 ? nsel_limits - 2 : 0);
+  if (E->cap_contacts > 0 && nact > capc) { /* keep the deepest (ties: lower id) */
+    int keep[NPT_MAX];
     for (int a = 0; a < nact; a++) {
       int rank = 0;
-      for (int b = 0; b < nact; b++)
-        if (dist[act[b]] < dist[act[a]] || (dist[act[b]] == dist[act[a]] && act[b] < act[a])) rank++;
-      keep[a] = rank < MAX_CONTACTS;
+      for (int b2 = 0; b2 < nact; b2++)
+        if (cp[b2].dist < cp[a].dist || (cp[b2].dist == cp[a].dist && cp[b2].id < cp[a].id)) rank++;
+      keep[a] = rank < capc;
     }
     int m = 0;
-    for (int a = 0; a < nact; a++) if (keep[a]) act[m++] = act[a];
+    for (int a = 0; a < nact; a++) if (keep[a]) cp[m++] = cp[a];
     nact = m;
   }
+  E->last_counts[4 * ei + 1] = nact;
 
   /* --- unconstrained forward dynamics: u* = u + dt M^-1 (tau - h)  (K1) */
   double M[NV_MAX * NV_MAX], h[NV_MAX], rhsv[NV_MAX], udot[NV_MAX], u[NV_MAX];
@@ -307,27 +447,7 @@ static void substep(oracle_env* E, int ei) {
   for (int j = 0; j < n; j++) u[6 + j] = s->qd[j];
   for (int k = 0; k < nv; k++) { u[k] += dt * udot[k]; clampv(&u[k], C->max_velocity); } /* K5 */
 
-  /* --- constraint rows: joint limits, contact normals, friction (K7) */
-  /* K5: at most MAX_LIMITS limit rows are solved -- the candidates (joint within LIMIT_WINDOW of a limit) with the SMALLEST
-   * margin, i.e. the most violated first (ties: lower joint, lower side), emitted in joint order.  (Until round 2 the first
-   * MAX_LIMITS in joint order were taken: a third joint could then run far past its limit unopposed and be thrown back at
-   * erp * violation / dt when a slot freed up -- robots launched metres into the air under a random policy.) */
-  row_t rows[MAX_ROWS]; int nr = 0;
-  int lim_sel[2 * SOLORL_MAX_DOF]; memset(lim_sel, 0, sizeof lim_sel);
-  {
-    double pens[2 * SOLORL_MAX_DOF]; int cand[2 * SOLORL_MAX_DOF], ncand = 0;
-    for (int j = 0; j < n; j++)
-      for (int side = 0; side < 2; side++) {
-        pens[2 * j + side] = side == 0 ? s->q[j] + C->joint_limit : C->joint_limit - s->q[j];
-        if (pens[2 * j + side] < LIMIT_WINDOW) cand[ncand++] = 2 * j + side;
-      }
-    for (int a = 0; a < ncand; a++) {
-      int rank = 0;
-      for (int b = 0; b < ncand; b++)
-        rank += pens[cand[b]] < pens[cand[a]] || (pens[cand[b]] == pens[cand[a]] && cand[b] < cand[a]);
-      lim_sel[cand[a]] = rank < MAX_LIMITS;
-    }
-  }
+  /* --- constraint rows: joint limits (selected above), contact normals, friction (K7) */
   for (int j = 0; j < n; j++) {
     for (int side = 0; side < 2; side++) {
       if (!lim_sel[2 * j + side]) continue;
@@ -338,27 +458,27 @@ static void substep(oracle_env* E, int ei) {
       r->rhs = pen; /* stash penetration; finished below */
     }
   }
-  int normal_row[NP_MAX];
+  int normal_row[NPT_MAX];
   for (int a = 0; a < nact; a++) {
-    int p = act[a];
     double nrm[3] = {0, 0, 1};
     row_t* r = &rows[nr]; memset(r, 0, sizeof *r);
-    point_jacobian_row(E, s, &K, prim_of(E, p)->link, P[p], nrm, r->J);
-    r->parent = -1; r->rhs = dist[p] + C->linear_slop; normal_row[a] = nr++;
+    point_jacobian_row(E, s, &K, cp[a].link, cp[a].P, nrm, r->J);
+    r->parent = -1; r->rhs = cp[a].dist + C->linear_slop; normal_row[a] = nr++;
   }
   int nnormal_end = nr;
   /* treadmill (reference simulation.py:45-77; model: include/solorl.h treadmill_*): a contact whose point lies on
    * the strip takes the strip's friction (Bullet combines by product); the feet sensor still reports it (plane contact) */
-  int on_strip[NP_MAX] = {0};
-  if (C->use_treadmill)
-    for (int a = 0; a < nact; a++) on_strip[act[a]] = fabs(P[act[a]][1] - s->treadmill_y) <= C->treadmill_half_width;
+  int on_strip[NPT_MAX];
+  for (int a = 0; a < nact; a++) on_strip[a] = C->use_treadmill && fabs(cp[a].P[1] - s->treadmill_y) <= C->treadmill_half_width;
   for (int a = 0; a < nact; a++) {
-    int p = act[a];
     for (int d = 0; d < 2; d++) {
+      /* friction directions: world x then y (model 0, the engine's order); model 1: btPlaneSpace1 of the normal (0,0,1) gives
+       * (0,-1,0) then (1,0,0) [K] */
       double t[3] = {d == 0, d == 1, 0};
+      if (E->contact_model == 1) { t[0] = d == 1; t[1] = d == 0 ? -1 : 0; }
       row_t* r = &rows[nr++]; memset(r, 0, sizeof *r);
-      point_jacobian_row(E, s, &K, prim_of(E, p)->link, P[p], t, r->J);
-      r->parent = normal_row[a]; r->mu = prim_of(E, p)->friction * (on_strip[p] ? C->treadmill_friction : 1.0);
+      point_jacobian_row(E, s, &K, cp[a].link, cp[a].P, t, r->J);
+      r->parent = normal_row[a]; r->mu = cp[a].friction * (on_strip[a] ? C->treadmill_friction : 1.0);
     }
   }
   double dV[NV_MAX]; memset(dV, 0, sizeof dV);
@@ -377,7 +497,7 @@ static void substep(oracle_env* E, int ei) {
   }
   for (int a = 0; a < nact; a++) { /* warm start cached normal impulses */
     row_t* r = &rows[normal_row[a]];
-    r->lam = C->warmstart * s->lambda_prev[act[a]];
+    r->lam = C->warmstart * cp[a].lam0;
     for (int k = 0; k < nv; k++) dV[k] += r->B[k] * r->lam;
   }
   for (int it = 0; it < C->solver_iterations; it++) {
@@ -399,13 +519,26 @@ static void substep(oracle_env* E, int ei) {
   }
   if (nr == 0) E->last_iterations[ei] = 0;
   for (int k = 0; k < nv; k++) { u[k] += dV[k]; clampv(&u[k], C->max_velocity); }
-  for (int p = 0; p < E->np; p++) { s->lambda_prev[p] = 0; E->last_lambda[ei][p] = 0; }
+  for (int p = 0; p < NP_MAX; p++) { s->lambda_prev[p] = 0; E->last_lambda[ei][p] = 0; }
   s->contact_mask = 0;
   for (int a = 0; a < nact; a++) {
-    s->lambda_prev[act[a]] = rows[normal_row[a]].lam;
-    E->last_lambda[ei][act[a]] = rows[normal_row[a]].lam;
-    s->contact_mask |= 1 << act[a];
-    for (int f = 0; f < 4; f++) if (on_strip[act[a]] && E->md->foot_prim[f] == act[a]) s->contact_mask |= 1 << (24 + f);
+    const double lam = rows[normal_row[a]].lam;
+    if (cp[a].prim) {
+      const int p = cp[a].id;
+      s->lambda_prev[p] = lam; E->last_lambda[ei][p] = lam;
+      s->contact_mask |= 1 << p;
+      for (int f = 0; f < 4; f++) if (on_strip[a] && E->md->foot_prim[f] == p) s->contact_mask |= 1 << (24 + f);
+    } else {
+      /* manifold model: the impulse goes back into its manifold point; mask bit of a link's representative primitive (the feet
+       * sensor, solo.py:310-323, asks for ANY contact point of the foot link) */
+      E->man[(size_t)ei * NL_MAX + cp[a].link].lam[cp[a].id & 3] = lam;
+      for (int p = 0; p < E->np; p++)
+        if (prim_of(E, p)->link == cp[a].link) {
+          s->contact_mask |= 1 << p;
+          for (int f = 0; f < 4; f++) if (on_strip[a] && E->md->foot_prim[f] == p) s->contact_mask |= 1 << (24 + f);
+          break;
+        }
+    }
   }
 
   /* --- semi-implicit Euler position update with the new velocities (K1) */
@@ -497,6 +630,7 @@ static void env_reset(oracle_env* E, int i) {
   int rc = s->rng_counter;
   double g0 = s->goal[0], g1 = s->goal[1];
   memset(s, 0, sizeof *s);
+  memset(&E->man[(size_t)i * NL_MAX], 0, sizeof(manifold_t) * NL_MAX);
   s->rng_counter = rc; s->goal[0] = g0; s->goal[1] = g1;
   s->pos[2] = 0.35; s->quat[3] = 1.0;                  /* solo.py:52,292-293 */
   if (E->cfg.use_treadmill) {                          /* scene.reset -> Treadmill.reset, simulation.py:37-41,72-74: new side */
@@ -597,23 +731,33 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   E->st = (solorl_env_state*)calloc((size_t)num_envs, sizeof *E->st);
   E->last_lambda = calloc((size_t)num_envs, sizeof *E->last_lambda);
   E->last_iterations = calloc((size_t)num_envs, sizeof *E->last_iterations);
+  E->last_counts = calloc((size_t)num_envs * 4, sizeof *E->last_counts);
+  E->man = calloc((size_t)num_envs * NL_MAX, sizeof *E->man);
+  E->hulls = cfg->robot == SOLORL_ROBOT_SOLO12 ? ORACLE_HULLS_SOLO12 : ORACLE_HULLS_SOLO8;
+  E->contact_model = 0; E->cap_contacts = 0; E->cap_limits = 0; E->manifold_links = ~0u;
+  if (getenv("ORACLE_MANIFOLD_LINKS")) E->manifold_links = (unsigned)strtoul(getenv("ORACLE_MANIFOLD_LINKS"), NULL, 0);
+  if (getenv("ORACLE_LIMIT_WINDOW")) LIMIT_WINDOW = atof(getenv("ORACLE_LIMIT_WINDOW"));
+  if (getenv("ORACLE_CONTACT_MODEL")) E->contact_model = atoi(getenv("ORACLE_CONTACT_MODEL")) != 0;
   /* K6 measurement hook (tests/test_oracle_k6.py): ORACLE_NO_SHOULDERS=1 drops the Solo12 shoulder-housing discs
    * (primitives 20..23) again, i.e. the round-1 primitive set, so that what they change stays measurable */
   if (getenv("ORACLE_NO_SHOULDERS") && atoi(getenv("ORACLE_NO_SHOULDERS")) && E->np > 20) E->np = 20;
   for (int i = 0; i < num_envs; i++) { E->st[i].quat[3] = 1; E->st[i].pos[2] = 0.35; E->st[i].need_reset = 1; }
   return E;
 }
-void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E->last_iterations); free(E); }
+void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E->last_iterations); free(E->last_counts); free(E->man); free(E); }
 int oracle_last_iterations(const oracle_env* E, int i) { return E->last_iterations[i]; }
+void oracle_set_caps(oracle_env* E, int max_contacts, int max_limits) { E->cap_contacts = max_contacts; E->cap_limits = max_limits; }
+void oracle_set_contact_model(oracle_env* E, int model) { E->contact_model = model != 0; memset(E->man, 0, sizeof(manifold_t) * (size_t)E->N * NL_MAX); }
+void oracle_last_counts(const oracle_env* E, int i, int out[4]) { memcpy(out, &E->last_counts[4 * i], sizeof(int) * 4); }
 void oracle_dims(const oracle_env* E, int* o, int* a, int* n) { if (o) *o = E->O; if (a) *a = E->n; if (n) *n = E->N; }
 void oracle_set_threads(oracle_env* E, int t) { E->nthreads = t < 1 ? 1 : t; }
 void oracle_reset(oracle_env* E, double* obs) {
-#pragma omp parallel for schedule(dynamic, 8) num_threads(E->nthreads)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(E->nthreads)
   for (int i = 0; i < E->N; i++) { env_reset(E, i); E->st[i].need_reset = 0; calc_state(E, &E->st[i], obs + (size_t)i * E->O); }
 }
 void oracle_step(oracle_env* E, const double* actions, double* obs, double* rew, uint8_t* done, uint8_t* timeout,
                  uint8_t* success, int32_t* ep_len, double* ep_rew, double* goals, double* dr) {
-#pragma omp parallel for schedule(dynamic, 8) num_threads(E->nthreads)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(E->nthreads)
   for (int i = 0; i < E->N; i++)
     env_step(E, i, actions + (size_t)i * E->n, obs, rew, done, timeout, success, ep_len, ep_rew, goals, dr);
 }

@@ -50,6 +50,16 @@ void oracle_prim_points(const oracle_env* e, int i, double* out);
 void oracle_last_lambda(const oracle_env* e, int i, double* lambda_n /* [nprims] */);
 /* PGS iterations the last sub-step of env i ran (<= solver_iterations: early exit on the residual threshold, K7) */
 int oracle_last_iterations(const oracle_env* e, int i);
+/* Engine emulation for measurements (tests/test_oracle_caps.py): solve at most max_contacts contact points (the deepest) and
+ * max_limits joint-limit rows (the most violated) per sub-step, as the HIP engine's slot count does; 0 = no cap (default: the
+ * oracle, like Bullet, has none). */
+void oracle_set_caps(oracle_env* e, int max_contacts, int max_limits);
+/* 0 (default): the analytic support primitives the HIP engine uses; 1: Bullet's scheme [K6] -- the convex hull of every link's
+ * collision mesh against the plane, one new point per step into a persistent <= 4-point manifold (oracle/hull_data.h).
+ * Clears the manifolds.  (Env var ORACLE_CONTACT_MODEL=1 selects it at create.) */
+void oracle_set_contact_model(oracle_env* e, int model);
+/* last sub-step of env i: contact points found / solved, joint-limit candidates / solved */
+void oracle_last_counts(const oracle_env* e, int i, int out[4]);
 /* Philox4x32-10 (for RNG parity tests) */
 void oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                    uint32_t out[4]);

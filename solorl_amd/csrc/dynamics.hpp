@@ -26,12 +26,23 @@
 
 namespace solo {
 
+// Slots of the constraint solve.  A robot gets up to MAX_LIMITS = 4 joint-limit rows and MAX_CONTACTS = 8 contact points, but
+// limit rows 3 and 4 take the place of contact points: the contact cap is 8 - max(limit rows - 2, 0), so that the row count
+// stays <= 2 + 3 * 8 = 26 and the sweep keeps its 13 static slots (TeamRows).  Measured on the uncapped oracle (tests/test_oracle_caps.py,
+// random policies): > 8 contact points in < 0.01 % of env-steps, > 4 joints beyond their limits never in 600 k env-steps, > 2 in
+// 0.05-0.17 % -- two limit rows (rounds 1-2) changed the next joint angles of 0.2 % of env-steps by up to 0.4 rad.
 constexpr int MAX_CONTACTS = 8;
-constexpr int MAX_LIMITS = 2;
-constexpr int MAX_ROWS = MAX_LIMITS + 3 * MAX_CONTACTS;   // 26
+constexpr int MAX_LIMITS = 4;
+constexpr int LIM_SLOT_ROWS = 2;                          // limit rows in the sweep's own limit slot; the others sit at the first normal positions
+constexpr int MAX_ROWS = LIM_SLOT_ROWS + 3 * MAX_CONTACTS;   // 26
+SD int extra_limits(int nlt) { return nlt > LIM_SLOT_ROWS ? nlt - LIM_SLOT_ROWS : 0; }
+SD int contact_cap(int nlt) { return MAX_CONTACTS - extra_limits(nlt); }
 constexpr int ROW_CORE = 20;                              // Jh6 JL3 W6 Y3 rhs dinv
 constexpr int NPRIM = 24;                                // 12 base points, knee + foot per leg (12 + 2 leg + i), Solo12: shoulder housing per leg (20 + leg)
-constexpr double LIMIT_WINDOW = 0.5;
+// A joint-limit row exists while the joint is AT or BEYOND its limit (margin <= 0), as btMultiBodyJointLimitConstraint::createConstraintRows
+// (`if (penetration > 0) continue`) [K5]; rounds 1-2 opened a speculative row 0.5 rad before the limit, which made several joints
+// compete for the rows ten times as often (1.2-2.5 % of random-policy env-steps had more than two candidates, now 0.05-0.17 %).
+constexpr double LIMIT_WINDOW = 0.0;
 constexpr double DISC_EPS2 = 1e-12;
 
 // dev builds (-DSOLO_WAVE_TIMING, tools/dev/wave_hist.py): four time stamps per wavefront, kept in registers and written with
@@ -409,7 +420,35 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     if (pp.tm_on && fabs(ty + kneeP.y) <= pp.tm_hw) smask |= 1 << (12 + 2 * L);
     if (pp.tm_on && fabs(ty + footP.y) <= pp.tm_hw) smask |= 1 << (13 + 2 * L);
   });
-  if (__popc(mask) > MAX_CONTACTS) {   // keep the MAX_CONTACTS deepest (ties: lower primitive id)
+#pragma unroll
+  for (int p = 0; p < NPRIM; p++) C.dist[p] = dist[p];
+  // joint-limit rows (K5) come first: their count fixes the contact slots.  At most MAX_LIMITS are solved: the candidates
+  // (joint at or beyond a limit) with the smallest margin, i.e. the most violated first (ties: lower joint, lower side).
+  // Taking the first ones in joint order instead (rounds 1-2, two rows) let a third joint run radians past its limit
+  // unopposed and be thrown back at erp * violation / dt once a slot freed up: robots were launched metres into the air.
+  T lpen[2 * NQ];
+  int lcand = 0;
+#pragma unroll
+  for (int j = 0; j < NQ; j++) {
+    lpen[2 * j] = st.q[j] + pp.qlim; lpen[2 * j + 1] = pp.qlim - st.q[j];
+    if (lpen[2 * j] <= T(LIMIT_WINDOW)) lcand |= 1 << (2 * j);
+    if (lpen[2 * j + 1] <= T(LIMIT_WINDOW)) lcand |= 1 << (2 * j + 1);
+  }
+  int lsel = lcand;
+  if (__popc(lcand) > MAX_LIMITS) {
+    lsel = 0;                          // (statically indexed: a rolled loop would put lpen[] in scratch for every lane, every sub-step)
+    static_for<2 * NQ>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      int rank = 0;
+      static_for<2 * NQ>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b != a) rank += ((lcand >> b) & 1) && (lpen[b] < lpen[a] || (lpen[b] == lpen[a] && b < a));
+      });
+      if (((lcand >> a) & 1) && rank < MAX_LIMITS) lsel |= 1 << a;
+    });
+  }
+  const int capc = contact_cap(__popc(lsel));
+  if (__popc(mask) > capc) {   // keep the deepest (ties: lower primitive id)
     int keep = 0;
     static_for<NPRIM>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
@@ -418,39 +457,9 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
         constexpr int q = decltype(qc)::value;
         if constexpr (q != p) rank += ((mask >> q) & 1) && (dist[q] < dist[p] || (dist[q] == dist[p] && q < p));
       });
-      if (((mask >> p) & 1) && rank < MAX_CONTACTS) keep |= 1 << p;
+      if (((mask >> p) & 1) && rank < capc) keep |= 1 << p;
     });
     mask = keep;
-  }
-#pragma unroll
-  for (int p = 0; p < NPRIM; p++) C.dist[p] = dist[p];
-  // joint-limit rows (K5) come first: their count fixes the contact slots.  At most MAX_LIMITS are solved: the candidates
-  // (joint within LIMIT_WINDOW of a limit) with the smallest margin, i.e. the most violated first (ties: lower joint, lower
-  // side).  Taking the first MAX_LIMITS in joint order instead (rounds 1-2) let a third joint run radians past its limit
-  // unopposed and be thrown back at erp * violation / dt once a slot freed up: robots were launched metres into the air.
-  T lpen[2 * NQ];
-  int lcand = 0;
-#pragma unroll
-  for (int j = 0; j < NQ; j++) {
-    lpen[2 * j] = st.q[j] + pp.qlim; lpen[2 * j + 1] = pp.qlim - st.q[j];
-    if (lpen[2 * j] < T(LIMIT_WINDOW)) lcand |= 1 << (2 * j);
-    if (lpen[2 * j + 1] < T(LIMIT_WINDOW)) lcand |= 1 << (2 * j + 1);
-  }
-  int lsel = lcand;
-  if (__popc(lcand) > MAX_LIMITS) {
-    // the two smallest margins in one ascending pass (strict comparisons: ties stay with the lower index)
-    static_assert(MAX_LIMITS == 2, "two-smallest scan");
-    T m1 = T(1e30), m2 = T(1e30);
-    int i1 = -1, i2 = -1;
-#pragma unroll
-    for (int a = 0; a < 2 * NQ; a++) {
-      if ((lcand >> a) & 1) {
-        const T pa = lpen[a];
-        if (pa < m1) { m2 = m1; i2 = i1; m1 = pa; i1 = a; }
-        else if (pa < m2) { m2 = pa; i2 = a; }
-      }
-    }
-    lsel = (1 << i1) | (1 << i2);
   }
   C.mask = mask; C.nc = __popc(mask); C.nlim_total = __popc(lsel); C.lsel = lsel;
   C.smask = smask & mask;
@@ -1089,7 +1098,7 @@ SNI void phase_integrate(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned ns
 //   bc   [4][BC]       base-solve broadcast block (Lam 36, u*_base 6, leg rates 12, a0 6)
 enum { E_JB = 0, E_JL = 6, E_BB = 9, E_BL = 15, E_RHS = 18, E_LEG = 19 };
 template <typename T, typename LDS> struct TeamRows {
-  static_assert(MAX_LIMITS == 2 && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
+  static_assert(LIM_SLOT_ROWS == 2 && MAX_LIMITS <= LIM_SLOT_ROWS + MAX_CONTACTS && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
   static constexpr int NPOS0 = 2, FPOS0 = NPOS0 + MAX_CONTACTS;              // first normal / friction position
   static constexpr int NSLOT = 1 + MAX_CONTACTS / 2 + MAX_CONTACTS;          // 13
   static constexpr int TR = 2 * NSLOT, BC = 60;
@@ -1099,13 +1108,19 @@ template <typename T, typename LDS> struct TeamRows {
   static constexpr size_t bytes = off_ctx;
   SD static T* lam(int col) { return reinterpret_cast<T*>(solo_smem + off_lam) + col; }            // + pos*4
   SD static T* bc(int col) { return reinterpret_cast<T*>(solo_smem + off_bc) + col * BC; }         // Lam 36, ub 6, leg rates 12, a0 6
+  // Limit rows beyond the limit slot's two (ne = extra_limits(nlt)) sit at the FIRST normal positions -- the solver order stays
+  // [limits | normals | friction pairs] -- and shift the contacts: contact k has its normal at position NPOS0 + ne + k and its friction
+  // pair at FPOS0 + 2 (ne + k); the friction positions of the first ne "contacts" stay empty (null rows).
   SD static int pos_of(int r, int nlt, int nc) {   // solver row index -> position
-    return r < nlt ? r : (r < nlt + nc ? NPOS0 + (r - nlt) : FPOS0 + (r - nlt - nc));
+    const int ne = extra_limits(nlt), nl0 = nlt - ne;
+    return r < nl0 ? r : (r < nlt ? NPOS0 + (r - nl0) : (r < nlt + nc ? NPOS0 + ne + (r - nlt) : FPOS0 + 2 * ne + (r - nlt - nc)));
   }
   // position -> solver row index, or -1 where the team has no row (null row)
   SD static int row_of(int pos, int nlt, int nc) {
-    const int kn = pos - NPOS0, kf = pos - FPOS0;
-    return pos < NPOS0 ? (pos < nlt ? pos : -1) : (pos < FPOS0 ? (kn < nc ? nlt + kn : -1) : (kf < 2 * nc ? nlt + nc + kf : -1));
+    const int ne = extra_limits(nlt), nl0 = nlt - ne;
+    const int kn = pos - NPOS0, kf = pos - FPOS0 - 2 * ne;
+    return pos < NPOS0 ? (pos < nl0 ? pos : -1)
+                       : (pos < FPOS0 ? (kn < ne ? nl0 + kn : (kn - ne < nc ? nlt + (kn - ne) : -1)) : ((kf >= 0 && kf < 2 * nc) ? nlt + nc + kf : -1));
   }
 };
 
@@ -1191,13 +1206,13 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   if (valid && t < NQ) {    // joint limits: bit 2j = lower window, 2j+1 = upper window (same order as the row slots)
     const T q = st.q[t];
-    if (q + pp.qlim < T(LIMIT_WINDOW)) lbits |= 1 << (2 * t);
-    if (pp.qlim - q < T(LIMIT_WINDOW)) lbits |= 1 << (2 * t + 1);
+    if (q + pp.qlim <= T(LIMIT_WINDOW)) lbits |= 1 << (2 * t);
+    if (pp.qlim - q <= T(LIMIT_WINDOW)) lbits |= 1 << (2 * t + 1);
   }
   int mask = team_or16(bits);
   lbits = team_or16(lbits);
   if (__popc(lbits) > MAX_LIMITS) {
-    // more joints at their limits than limit rows (K5 solves MAX_LIMITS): the smallest margins, i.e. the most violated, win
+    // more joints at their limits than limit rows (MAX_LIMITS): the smallest margins, i.e. the most violated, win
     // (ties: lower joint, lower side) -- same rule as phase_detect, see there.  Lane t ranks its own joint's two sides against
     // the team's margins in LDS.
     if (valid && t < NQ) { C.limpen[2 * t] = st.q[t] + pp.qlim; C.limpen[2 * t + 1] = pp.qlim - st.q[t]; }
@@ -1220,8 +1235,9 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     lbits = team_or16(sel);
   }
   if (pp.tm_on) sbits = team_or16(sbits);     // (uniform branch)
-  if (__popc(mask) > MAX_CONTACTS) {
-    // more than MAX_CONTACTS primitives touch (a robot lying on the ground -- the heaviest wavefronts, which set the launch
+  const int capc = contact_cap(__popc(lbits));   // limit rows 3 and 4 take the place of contact points (see MAX_LIMITS)
+  if (__popc(mask) > capc) {
+    // more primitives touch than there are contact slots (a robot lying on the ground -- the heaviest wavefronts, which set the launch
     // time): keep the deepest, ties to the lower id.  Lane t ranks primitives t and t+16 against the team's distances in LDS
     // (the serial version on the leader was a 1 900-instruction non-inlined call that also made this phase save registers on
     // every call).
@@ -1235,7 +1251,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
           const T dq = C.dist[q];
           rank += (((mask >> q) & 1) && (dq < dp || (dq == dp && q < p))) ? 1 : 0;
         }
-        if (rank < MAX_CONTACTS) keep |= 1 << p;
+        if (rank < capc) keep |= 1 << p;
       }
     }
     mask = team_or16(keep);
@@ -1328,7 +1344,7 @@ SD void phase_legrates_team(CH ch, const PhysParams<T> pp, const LDS lds, int t)
 template <typename T, typename LDS> SD void team_counts(const LDS& lds, int& nlt, int& nc, int& ncmax, int& anylim) {
   const T* hdr = lds.hdr();
   nlt = (int)hdr[0]; nc = (int)hdr[LDS::LANES];
-  int m = nc | (nlt << 8);
+  int m = (nc + extra_limits(nlt)) | (nlt << 8);       // normal positions in use: the contacts behind the extra limit rows
 #pragma unroll
   for (int o = 32; o >= 16; o >>= 1) { int v = __shfl_xor(m, o); m = ((v & 255) > (m & 255) ? (v & 255) : (m & 255)) | ((v | m) & ~255); }
   m = __builtin_amdgcn_readfirstlane(m);          // identical in all lanes: scalar branches in the sweep
@@ -1648,8 +1664,9 @@ SNI_SCALAR void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev,
   const T dt = pp.dt;
   const int mask = C.mask;
   const T* lam = TRW::lam(lds.lane);
+  const int npos0 = TRW::NPOS0 + extra_limits(C.nlim_total);
   for (int p = t; p < NPRIM; p += 16) {       // warm-start cache: normal impulse of primitive p (its rank among the contacts)
-    const T l = ((mask >> p) & 1) ? lam[(TRW::NPOS0 + __popc(mask & ((1 << p) - 1))) * 4] : T(0);
+    const T l = ((mask >> p) & 1) ? lam[(npos0 + __popc(mask & ((1 << p) - 1))) * 4] : T(0);
     C.lamp[p] = l;
   }
   const T* hdr = lds.hdr();
