@@ -18,13 +18,17 @@ exactly K steps; max over ranks per repeat).  `roofline.kernel_ms_avg` comes fro
 stream around the SAME replays, so it can never exceed ms_per_step.
 
 Prints ONE JSON line: value = whole-job env-steps/s, `roofline` (algorithmic bytes of SURVEY.md 8d / that kernel time;
-HBM traffic, VALU issue rate and FP32 rate from the committed rocprofv3 PMC passes), `cpu_baseline` (the fp64 oracle
-timed on the host cores on a bounded sample, all cores and one thread; rank 0, N=1 only) and `ppo_loop` (the full PPO
-iteration of BASELINE config 3 with the README recipe; with N > 1 every optimizer step carries the 80 KB RCCL
-all-reduce of the flat gradient bucket).
+HBM traffic, VALU issue rate and FP32 rate from the committed rocprofv3 PMC passes -- only while the loaded library IS the
+one they were measured on, by hash), `f64` (the same workload on the engine's double-precision instantiation: the reference's
+arithmetic is fp64 until agents/ppo/envs.py:192), `cpu_baseline` (the fp64 oracle timed on the host cores per BASELINE.md
+section 3: 64 and 4096 envs, median of 5, all granted cores and one thread; rank 0, N=1 only) and `ppo_loop` (the full PPO
+iteration of BASELINE config 3 with the README recipe, median of 3 iterations; with N > 1 every optimizer step carries the
+80 KB RCCL all-reduce of the flat gradient bucket).
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import socket
 import statistics
@@ -41,7 +45,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0   # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32, 2 cycles each (a LONE wave sustains 4)
 REPEATS = 5
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def algorithmic_bytes_per_env_step(A, S, C, O, hist_state, n_dr=5, n_counters=2):
@@ -57,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64", action="store_true", help="skip the fp64-instantiation leg")
     ap.add_argument("--ppo-steps", type=int, default=400, help="rollout length of the PPO-loop leg (0 = skip); README: num_steps = episode_length")
     ap.add_argument("--ppo-epoch", type=int, default=5, help="PPO epochs of that leg (README: 5)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -84,37 +89,68 @@ def spawn_ranks(args, argv):
     return 0
 
 
-def cpu_baseline(cfg, budget_s=10.0):
-    """Oracle (fp64 CPU restatement, kind 'port') on a bounded sample of the same workload: all granted cores
-    (OpenMP over envs) and a single thread."""
+def granted_cores():
+    """CPU share of this process: the affinity mask, cut down to the cgroup's CPU quota where one is set (the GPU box grants a
+    share of its host: more runnable threads than quota are throttled, which is what made 64 OpenMP threads only 7 x one)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(float(txt[0]) / float(txt[1])))))
+            else:
+                q = float(txt[0]); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(math.ceil(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, int(os.environ.get("SOLORL_CPU_THREADS", "256"))))
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """Oracle (fp64 CPU restatement, kind 'port') on the same workload, protocol of BASELINE.md section 3: 64 and 4096 envs,
+    50 warm-up env-steps, >= 2000 measured env-steps per repetition, median of 5 repetitions; all granted cores (OpenMP over
+    envs) and a single thread.  The budget is kept by the number of control steps per repetition, never by the env count."""
     import numpy as np
     from oracle.oracle_py import Oracle
-    try:
-        cores = len(os.sched_getaffinity(0))      # the GPU box grants a CPU share, not the whole host
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = min(cores, int(os.environ.get("SOLORL_CPU_THREADS", "64")))
+    cores = granted_cores()
 
     def run(threads, N, budget):
-        orc = Oracle(cfg, N, seed=1, threads=threads)
+        orc = Oracle(cfg, N, seed=1, threads=cores)          # (the untimed reset = 5-11 settle steps per env runs on all cores)
         orc.reset()
+        orc.L.oracle_set_threads(orc.h, threads)
         rng = np.random.default_rng(0)
         acts = rng.uniform(-1, 1, size=(8, N, orc.A))
-        orc.step(acts[0])
-        t0 = time.perf_counter(); steps = 0
-        while True:
-            orc.step(acts[steps % 8]); steps += 1
-            el = time.perf_counter() - t0
-            if el > budget or steps >= 2000:
-                break
-        return N * steps / el, steps, el
+        t0 = time.perf_counter()
+        for k in range(max(1, -(-50 // N))):                 # >= 50 warm-up env-steps
+            orc.step(acts[k % 8])
+        per_step = (time.perf_counter() - t0) / max(1, -(-50 // N))
+        steps = max(-(-2000 // N), min(200, int(budget / 5.0 / max(per_step, 1e-6))))      # >= 2000 env-steps per repetition
+        reps, t = [], 0
+        for r in range(5):
+            t0 = time.perf_counter()
+            for k in range(steps):
+                orc.step(acts[t % 8]); t += 1
+            reps.append(N * steps / (time.perf_counter() - t0))
+        return {"value": statistics.median(reps), "unit": "env-steps/s", "cores": threads, "envs": N, "steps_per_repetition": steps,
+                "env_steps_per_repetition": N * steps, "repetitions": 5, "min": min(reps), "max": max(reps)}
 
-    v, steps, el = run(cores, 16 * cores, budget_s)
-    v1, steps1, el1 = run(1, 16, budget_s / 2)
-    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d Solo12-walk envs x %d control steps, random policy, OpenMP over envs (%.1f s)" % (16 * cores, steps, el),
-            "single_thread": {"value": v1, "unit": "env-steps/s", "cores": 1,
-                              "sample": "16 envs x %d control steps (%.1f s)" % (steps1, el1)}}
+    all_4096 = run(cores, 4096, budget_s * 0.35)
+    all_64 = run(min(cores, 64), 64, budget_s * 0.1)
+    one_64 = run(1, 64, budget_s * 0.2)
+    one_4096 = run(1, 4096, budget_s * 0.35)
+    return {"value": all_4096["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "fp64 oracle, %d Solo12-walk envs x %d control steps x 5 repetitions (median), random policy, OpenMP over envs, %d threads"
+                      % (4096, all_4096["steps_per_repetition"], cores),
+            "protocol": "BASELINE.md section 3: 50 warm-up env-steps, >= 2000 measured env-steps, median of 5",
+            "all_cores": {"envs_4096": all_4096, "envs_64": all_64},
+            "single_thread": {"envs_4096": one_4096, "envs_64": one_64},
+            "thread_scaling_4096": all_4096["value"] / one_4096["value"]}
 
 
 def ppo_leg(env, dev, world, T, epochs):
@@ -155,19 +191,26 @@ def ppo_leg(env, dev, world, T, epochs):
         return t_roll, time.perf_counter() - t0
 
     iteration()                     # captures both graphs (and trains one step)
-    t_roll, t_all = iteration()
-    if world > 1:
-        tt = torch.tensor([t_roll, t_all], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_roll, t_all = tt.tolist()
+    runs = []
+    for _ in range(3):              # median of three timed iterations (max over ranks each)
+        t_roll, t_all = iteration()
+        if world > 1:
+            tt = torch.tensor([t_roll, t_all], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_roll, t_all = tt.tolist()
+        runs.append((t_all, t_roll))
+    runs.sort()
+    t_all, t_roll = runs[1]
     out = {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
+           "iterations_timed": 3, "statistic": "median iteration", "iteration_ms": [1e3 * r[0] for r in runs],
+           "allreduce_in_graph": (not getattr(agent, "_split", True)) if world > 1 else None,
            "ppo_epoch": epochs, "mini_batches_per_epoch": (T * N) // mb, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
            "note": "policy act (solorl_policy_act) + env.step writing into the rollout storage per step, then GAE + PPO epochs (solorl_ppo_grad_stage1/2 + clip + Adam per mini-batch); rollout and mini-batch step replayed from HIP graphs"}
     if world > 1:                   # the collective of the data-parallel PPO step, timed on its own
         reps = 50
         sync(); t0 = time.perf_counter()
         for _ in range(reps):
-            agent.bucket.all_reduce_mean()
+            agent.bucket.all_reduce_sum()
         sync()
         out["grad_allreduce"] = {"bytes": agent.bucket.flat.numel() * 4, "us_per_call": 1e6 * (time.perf_counter() - t0) / reps,
                                  "calls_per_update": out["optimizer_steps"], "backend": dist.get_backend()}
@@ -283,8 +326,33 @@ def main(argv=None):
         # BASELINE config 3 / 4: the full PPO loop (rollout + GAE + clipped update) on the same engine; never fatal
         try:
             ppo = ppo_leg(env, dev, world, args.ppo_steps, args.ppo_epoch)
-        except Exception as ex:     # (ranks run identical code on identical devices: a failure here is symmetric, nobody is
-            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}     #  left waiting in a collective; the headline line is still printed)
+        except Exception as ex:     # never fatal for the headline line.  A failure on ONE rank leaves the others inside a collective
+            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}     # of the leg: they time out with the process group (NCCL watchdog),
+        if world > 1 and not all_ranks("error" not in (ppo or {})):   # and every rank that does return agrees on the outcome before
+            ppo = ppo if (ppo and "error" in ppo) else {"error": "the PPO leg failed on another rank"}     # any further collective
+
+    # the same workload on the engine's fp64 instantiation (the reference's arithmetic type), single repeat of <= 100 steps
+    f64 = None
+    if not args.no_f64:
+        try:
+            from solorl_amd.config import PRECISION_F64
+            c64 = cfg.copy(); c64.precision = PRECISION_F64
+            e64 = SoloVecEnv(c64, N, device=dev, seed=1, env_id_offset=rank * N)
+            e64.reset()
+            for t in range(burn_in):
+                e64.step_inplace(acts[t % R])
+            K64 = min(K, 100)
+            barrier(); t0 = time.perf_counter()
+            for t in range(K64):
+                e64.step_inplace(acts[t % R])
+            barrier(); el64 = time.perf_counter() - t0
+            if world > 1:
+                t_ = torch.tensor([el64], device=dev, dtype=torch.float64); dist.all_reduce(t_, op=dist.ReduceOp.MAX); el64 = float(t_.item())
+            f64 = {"value": world * N * K64 / el64, "unit": "env-steps/s", "ms_per_step": 1e3 * el64 / K64, "steps": K64, "dtype": "f64",
+                   "launch": "eager", "note": "step_kernel_team<double,solo12>, same workload and burn-in; parity-tested against the oracle to rounding"}
+            e64.close()
+        except Exception as ex:
+            f64 = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0:
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
@@ -299,6 +367,9 @@ def main(argv=None):
             "config": {"workload": "solo12_walk_%denvs_per_gpu_random_policy_sim_only" % N, "robot": "solo12",
                        "task": "walk", "envs_per_gpu": N, "frame_skip": 4, "episode_length": EPISODE_LENGTH,
                        "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world, "launch": launch,
+                       "solver": {"iterations_max": cfg.solver_iterations, "residual_threshold": cfg.solver_residual_threshold,
+                                  "warmstart": cfg.warmstart, "note": "PyBullet defaults: 50 iterations, solverResidualThreshold 1e-7; no multibody warm start"},
+                       "engine": {k: env.get_property(k) for k in ("lanes_per_env", "sweep_variant", "max_contacts", "max_limit_rows")},
                        "burn_in_steps": burn_in, "repeats": REPEATS, "statistic": "median of %d repeats of exactly %d steps" % (REPEATS, K)},
             "repeats_ms_per_step": [1e3 * w / K for w in walls],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -308,10 +379,19 @@ def main(argv=None):
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "path is FP32-VALU issue / dependency bound (SURVEY 8d), see valu_issue and fp32; HBM fraction is small by construction"},
         }
-        if os.path.exists(TRAFFIC_FILE) and N == ENVS_PER_GPU:
-            # per-launch figures from the committed rocprofv3 --pmc passes (profiles/r02_pmc_*.txt), steady state, 4096 envs
-            prof = json.load(open(TRAFFIC_FILE))
+        prof = json.load(open(TRAFFIC_FILE)) if os.path.exists(TRAFFIC_FILE) else None
+        from solorl_amd import _native
+        lib_hash = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
+        out["roofline"]["lib_sha256_16"] = lib_hash
+        if prof is not None and (prof.get("lib_sha256_16") != lib_hash or N != ENVS_PER_GPU):
+            # the counters belong to another build of the engine (or another batch size): do not carry them
+            out["roofline"]["pmc_note"] = "PMC-derived fields omitted: %s was measured on library %s, loaded library is %s" % (
+                os.path.basename(TRAFFIC_FILE), prof.get("lib_sha256_16"), lib_hash)
+            prof = None
+        if prof is not None:
+            # per-launch figures from the committed rocprofv3 --pmc passes (profiles/r03_pmc_*.txt), steady state, 4096 envs, SAME library
             rf = out["roofline"]
+            rf["pmc_source"] = os.path.relpath(TRAFFIC_FILE, ROOT)
             rf["traffic"] = prof.get("bytes_per_launch")
             if "valu_insts_per_launch" in prof:
                 rate = prof["valu_insts_per_launch"] / (k_avg * 1e-3)
@@ -323,6 +403,8 @@ def main(argv=None):
                 rf["fp32"] = {"achieved_tflops": fl / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TF, "frac": fl / 1e12 / FP32_VECTOR_PEAK_TF,
                               "flops_per_launch": prof["fp32_flops_per_launch"], "flops_per_env_step": prof["fp32_flops_per_launch"] / N,
                               "count": prof.get("fp32_flops_note", "")}
+        if f64 is not None:
+            out["f64"] = f64
         if ppo is not None:
             out["ppo_loop"] = ppo
         if world == 1 and not args.no_cpu_baseline:

@@ -22,7 +22,7 @@
  *                             pre-activation gradient (what `loss.backward()` computes before the weight-gradient GEMMs)
  *   solorl_ppo_grad_stage2 <- the weight-gradient products of that backward pass, written into the parameters' gradients
  *   solorl_ppo_clip_adam   <- agents/ppo/ppo.py:75-77 (clip_grad_norm_ + optimizer.step) on the MLP's 13 parameter tensors
- *   solorl_get_state / solorl_set_state : no reference counterpart (parity-test hooks)
+ *   solorl_get_state / solorl_set_state / solorl_get_property : no reference counterpart (parity-test hooks, run records)
  *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
  *
  * Plain pointers and sizes only; no torch types.  All array arguments are DEVICE pointers
@@ -176,6 +176,14 @@ int solorl_step(solorl_env* env, const float* actions /* [N*A] */, float* obs_ou
 int solorl_get_observation(solorl_env* env, float* obs_out, void* stream);
 int solorl_increment_curriculum(solorl_env* env, double value);
 
+/* Read-only properties of a handle (no reference counterpart): how this handle's batch is mapped and solved, so that a benchmark
+ * or a scaling run can record and pin what it measured.  Names: "lanes_per_env" (16 team mode / 1 lane mode), "sweep_variant"
+ * (2: PGS sweep with the K7 residual exit -- the default, one variant at every batch size; 1 / 0: fixed-iteration sweep,
+ * software-pipelined / plain -- chosen by grid size when solver_residual_threshold = 0 unless SOLORL_PGS_PIPE pins it, the last bits
+ * of an env then depend on which side of one wavefront per SIMD its batch is), "max_contacts", "max_limit_rows", "f64".
+ * Unknown name: SOLORL_ERR_INVALID. */
+int solorl_get_property(const solorl_env* env, const char* name, double* value);
+
 int solorl_get_state(solorl_env* env, int env_index, solorl_env_state* out /* host */);
 int solorl_set_state(solorl_env* env, int env_index, const solorl_env_state* in /* host */);
 
@@ -259,13 +267,16 @@ int solorl_ppo_grad_count(int obs_dim, int act_dim);
  * bias-corrected, eps outside the square root, L2 weight_decay added to the gradient, no amsgrad).  The parameters behind `p`
  * are UPDATED IN PLACE; exp_avg / exp_avg_sq hold solorl_ppo_grad_count(obs_dim, act_dim) + act_dim floats in the order of
  * solorl_policy_params' pointers; step [1] is incremented; lr [1] is read from the device (a schedule may rewrite it between
- * calls); offset (optional) is advanced by offset_increment -- the mini-batch cursor of solorl_ppo_batch. */
+ * calls); offset (optional) is advanced by offset_increment -- the mini-batch cursor of solorl_ppo_batch.  grad_scale folds the
+ * 1 / world_size of a data-parallel gradient mean into the same launch. */
 typedef struct solorl_adam_state {
   float *exp_avg, *exp_avg_sq, *step;
   const float* lr;
   int64_t* offset;
   int64_t offset_increment;
-  float beta1, beta2, eps, weight_decay, max_grad_norm /* <= 0: no clipping */, reserved0;
+  float beta1, beta2, eps, weight_decay, max_grad_norm /* <= 0: no clipping */;
+  float grad_scale;   /* every gradient element is multiplied by this before the norm and the update: 1 / world_size after a SUMMED
+                       * all-reduce of the flat bucket (data-parallel mean); <= 0 is read as 1 */
 } solorl_adam_state;
 int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* g, const solorl_adam_state* a, int device_id, void* stream);
 

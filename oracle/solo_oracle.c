@@ -751,13 +751,18 @@ void oracle_set_contact_model(oracle_env* E, int model) { E->contact_model = mod
 void oracle_last_counts(const oracle_env* E, int i, int out[4]) { memcpy(out, &E->last_counts[4 * i], sizeof(int) * 4); }
 void oracle_dims(const oracle_env* E, int* o, int* a, int* n) { if (o) *o = E->O; if (a) *a = E->n; if (n) *n = E->N; }
 void oracle_set_threads(oracle_env* E, int t) { E->nthreads = t < 1 ? 1 : t; }
+/* OpenMP over envs (independent units): dynamic chunks -- an env-step costs 2-10 x more with contacts than in free flight -- of up to 16
+ * envs (whole cache lines of the int32 / double output arrays), smaller when there are few envs per thread (64 envs on 16 threads) */
+static int omp_chunk(const oracle_env* E) { int c = E->N / (4 * E->nthreads); return c < 1 ? 1 : (c > 16 ? 16 : c); }
 void oracle_reset(oracle_env* E, double* obs) {
-#pragma omp parallel for schedule(dynamic, 16) num_threads(E->nthreads)
+  const int chunk = omp_chunk(E);
+#pragma omp parallel for schedule(dynamic, chunk) num_threads(E->nthreads)
   for (int i = 0; i < E->N; i++) { env_reset(E, i); E->st[i].need_reset = 0; calc_state(E, &E->st[i], obs + (size_t)i * E->O); }
 }
 void oracle_step(oracle_env* E, const double* actions, double* obs, double* rew, uint8_t* done, uint8_t* timeout,
                  uint8_t* success, int32_t* ep_len, double* ep_rew, double* goals, double* dr) {
-#pragma omp parallel for schedule(dynamic, 16) num_threads(E->nthreads)
+  const int chunk = omp_chunk(E);
+#pragma omp parallel for schedule(dynamic, chunk) num_threads(E->nthreads)
   for (int i = 0; i < E->N; i++)
     env_step(E, i, actions + (size_t)i * E->n, obs, rew, done, timeout, success, ep_len, ep_rew, goals, dr);
 }

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 
 # every symbol include/solorl.h declares
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
-           "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state",
+           "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state", "solorl_get_property",
            "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_ppo_clip_adam", "solorl_last_error", "solorl_version")
 
 
@@ -38,7 +38,7 @@ class PpoGrads(C.Structure):                # solorl_ppo_grads
 class AdamState(C.Structure):               # solorl_adam_state
     _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step", C.c_void_p), ("lr", C.c_void_p), ("offset", C.c_void_p),
                 ("offset_increment", C.c_int64), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
-                ("max_grad_norm", C.c_float), ("reserved0", C.c_float)]
+                ("max_grad_norm", C.c_float), ("grad_scale", C.c_float)]
 
 
 class PpoStage1(C.Structure):               # solorl_ppo_stage1
@@ -68,6 +68,7 @@ def lib():
         L.solorl_increment_curriculum.argtypes = [C.c_void_p, C.c_double]
         L.solorl_get_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(EnvState)]
         L.solorl_set_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(EnvState)]
+        L.solorl_get_property.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
         L.solorl_ppo_loss.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p]
         L.solorl_compute_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -1542,9 +1542,11 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // K7 early exit, per env as in the reference (one Bullet world per env): a team whose sweep changed no row by more
   // than the threshold is finished -- its result is written back right then (it keeps sweeping along with its wavefront,
   // which costs nothing and is never read) -- and the wavefront leaves the loop once all four teams are finished.
-  const unsigned team_bit = 1u << col;                                // this lane's team
-  unsigned finished = 0;                                              // wave-uniform set of finished teams (4 bits)
-#pragma unroll 1
+  // Bookkeeping per sweep: the lanes' flags are OR-ed over the team with four DPP steps and one compare / branch decides whether
+  // any team became quiet in this sweep (round 2 split the wave's ballot into four team masks on the scalar unit: ~25 instructions
+  // per sweep, a twelfth of a 6-slot sweep; now ~9).
+  bool fin = false;                                                   // this lane's team is finished (uniform within the team)
+#pragma unroll 1                                                    // (unrolled by two: no change, measured)
   for (int it = 0; it < iterations; it++) {
     bool viol = false;
     static_for<n>([&](auto ic) {
@@ -1582,20 +1584,16 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       dpre = dnext; delp = del; delxp = delx;
     });
     if constexpr (EXIT) {
-      // lanes of a team sit in one 16-lane row of the wavefront: bits 16c .. 16c+15 of the ballot belong to team c
-      const unsigned long long vm = __ballot(viol);
-      unsigned quiet = 0;
-#pragma unroll
-      for (int c = 0; c < 4; c++) quiet |= ((unsigned)(vm >> (16 * c)) & 0xFFFFu) == 0u ? (1u << c) : 0u;
-      const unsigned newly = quiet & ~finished;
-      if (newly) {                                       // (wave-uniform branch, taken at most once per team)
-        if (newly & team_bit) SOLO_PGS_WRITE_BACK();
-        finished |= newly;
-        if (finished == 0xFu) break;
+      const bool quiet = team_or16(viol ? 1 : 0) == 0;                 // no lane of this team saw a change above its row's threshold
+      const bool nw = quiet && !fin;
+      if (__any(nw)) {                                               // (wave-uniform branch, taken at most once per team)
+        if (nw) SOLO_PGS_WRITE_BACK();
+        fin = fin || quiet;
+        if (__all(fin)) break;
       }
     }
   }
-  if constexpr (EXIT) { if (!(finished & team_bit)) SOLO_PGS_WRITE_BACK(); }     // teams that ran all the iterations
+  if constexpr (EXIT) { if (!fin) SOLO_PGS_WRITE_BACK(); }     // teams that ran all the iterations
   else SOLO_PGS_WRITE_BACK();
 #undef SOLO_PGS_WRITE_BACK
 }

@@ -1233,6 +1233,24 @@ int solorl_dims(const solorl_env* h, int* obs_dim, int* act_dim, int* num_envs) 
   return 0;
 }
 
+int solorl_get_property(const solorl_env* h, const char* name, double* value) {
+  if (!h || !name || !value) return fail(SOLORL_ERR_INVALID, "null argument");
+  const std::string n(name);
+  if (n == "lanes_per_env") *value = h->team ? 16 : 1;
+  else if (n == "sweep_variant") {
+    if (h->cfg.solver_residual_threshold > 0) *value = 2;
+    else if (!h->team) *value = 1;          // (lane mode: one software-pipelined row loop)
+    else {
+      const int grid = (((h->N + 3) / 4) + 7) & ~7;
+      *value = h->pipe_override >= 0 ? h->pipe_override : (grid <= h->simds ? 1 : 0);
+    }
+  } else if (n == "max_contacts") *value = MAX_CONTACTS;
+  else if (n == "max_limit_rows") *value = MAX_LIMITS;
+  else if (n == "f64") *value = h->f64 ? 1 : 0;
+  else return fail(SOLORL_ERR_INVALID, "unknown property: " + n);
+  return 0;
+}
+
 int solorl_reset(solorl_env* h, float* obs_out, void* stream) {
   if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));

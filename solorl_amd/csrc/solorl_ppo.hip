@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Ar
 // nine small launches in PyTorch (norm, three scalar ops, scale, the multi-tensor Adam, the mini-batch cursor ...); here one
 // 1024-thread workgroup reads every gradient twice.
 struct AdamSeg { float* p; const float* g; int n, off; };
-struct AdamArgs { AdamSeg seg[13]; int total; float* m; float* v; float* step; const float* lr; float b1, b2, eps, wd, max_norm;
+struct AdamArgs { AdamSeg seg[13]; int total; float* m; float* v; float* step; const float* lr; float b1, b2, eps, wd, max_norm, gscale;
                   long long* offset; long long inc; };
 __global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(const AdamArgs K) {
   // (a variant with one flat element per (thread, slot) and all loads of a pass issued together was slower, 31 vs 22 us: finding
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(const AdamArgs K) {
   float ss = 0.f;
 #pragma unroll 1
   for (int s = 0; s < 13; ++s)
-    for (int i = tid; i < K.seg[s].n; i += 1024) { const float g = K.seg[s].g[i]; ss = fmaf(g, g, ss); }
+    for (int i = tid; i < K.seg[s].n; i += 1024) { const float g = K.seg[s].g[i] * K.gscale; ss = fmaf(g, g, ss); }
   ss = wave_sum(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(const AdamArgs K) {
   for (int s = 0; s < 13; ++s) {
     const AdamSeg& S = K.seg[s];
     for (int i = tid; i < S.n; i += 1024) {
-      float p = S.p[i], g = S.g[i] * coef;
+      float p = S.p[i], g = S.g[i] * K.gscale * coef;        // gscale: 1 / world after a SUMMED gradient all-reduce (the mean's scale, fused)
       if (K.wd != 0.f) g = fmaf(K.wd, p, g);
       const int j = S.off + i;
       const float m = K.m[j] + (1.0f - K.b1) * (g - K.m[j]);                 // exp_avg.lerp_(grad, 1 - beta1)
@@ -602,6 +602,7 @@ int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* 
   }
   K.total = off; K.m = a->exp_avg; K.v = a->exp_avg_sq; K.step = a->step; K.lr = a->lr;
   K.b1 = a->beta1; K.b2 = a->beta2; K.eps = a->eps; K.wd = a->weight_decay; K.max_norm = a->max_grad_norm;
+  K.gscale = a->grad_scale > 0.f ? a->grad_scale : 1.0f;
   K.offset = reinterpret_cast<long long*>(a->offset); K.inc = a->offset_increment;
   hipLaunchKernelGGL(ppo_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, K);
   return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_clip_adam_kernel launch");

@@ -57,6 +57,16 @@ class FlatGradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / w)
 
+    def all_reduce_sum(self):
+        """The collective alone (the consumer applies 1 / world itself: solorl_ppo_clip_adam's grad_scale); RCCL collectives can
+        be captured in a HIP graph, so with the nccl backend this call sits INSIDE the captured mini-batch step."""
+        if world() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
+def backend():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
 
 def global_mean_std(x, unbiased=True, eps=0.0):
     """mean/std of a tensor sharded over ranks == torch.mean/std of the concatenation."""

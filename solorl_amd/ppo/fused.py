@@ -189,7 +189,7 @@ class ClipAdam:
     (solorl_ppo_clip_adam) instead of nine; also advances the mini-batch cursor.  The learning rate is read from `lr`, a device
     tensor (the linear schedule rewrites it between updates); moments and the step count live here."""
 
-    def __init__(self, mini_batch_grad, lr, max_grad_norm, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, offset=None, offset_increment=0):
+    def __init__(self, mini_batch_grad, lr, max_grad_norm, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, offset=None, offset_increment=0, grad_scale=1.0):
         mb = mini_batch_grad
         dev = mb.psum.device
         n = _native.lib().solorl_ppo_grad_count(mb.P.obs_dim, mb.P.act_dim) + mb.P.act_dim
@@ -204,6 +204,7 @@ class ClipAdam:
         S.offset, S.offset_increment = (offset.data_ptr() if offset is not None else 0), int(offset_increment)
         S.beta1, S.beta2, S.eps, S.weight_decay = float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
         S.max_grad_norm = float(max_grad_norm) if max_grad_norm is not None else 0.0
+        S.grad_scale = float(grad_scale)     # 1 / world: the gradients arrive SUMMED over the ranks (FlatGradBucket.all_reduce_sum)
         self._offset = offset
 
     def __call__(self):

@@ -197,20 +197,60 @@ class GraphedPPO(PPO):
         self._stats.zero_(); self._off.zero_()
         if self._mb is not None:
             self._mb.reset()
-        self._split = D.world() > 1
+        # world > 1: one flat-bucket all-reduce per optimizer step, between the gradients and the clip.  With the nccl
+        # (= RCCL) backend the collective is CAPTURED with the rest, so a mini-batch step stays ONE graph replay (gradients ->
+        # ncclAllReduce(sum) -> clip + Adam with grad_scale = 1 / world in the same launch); a probe graph checks on every rank that a
+        # captured all-reduce really runs at replay, and all ranks agree on the outcome.  Otherwise (gloo rehearsal, a failed
+        # probe, SOLORL_SPLIT_ALLREDUCE=1): gradients graph -> eager all-reduce -> optimizer graph, as in round 2.
+        w = D.world()
+        self._split = False
+        if w > 1:
+            self._split = not self._collective_is_capturable(dev)
+        if self._ca is not None:
+            self._ca.S.grad_scale = 1.0 / w          # the bucket arrives SUMMED (all_reduce_sum); the scale is fused into the step
+        reduce_ = self.bucket.all_reduce_sum if self._ca is not None else self.bucket.all_reduce_mean
+        self._reduce = reduce_
         pool = torch.cuda.graph_pool_handle()
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1, pool=pool, **capture_kwargs()):
             fwd_bwd()
             if not self._split:
+                if w > 1:
+                    reduce_()
                 opt_step()
-        if self._split:                       # the RCCL all-reduce of the flat bucket runs between two graphs
+        if self._split:                       # the all-reduce of the flat bucket runs between two graphs
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g2, pool=pool, **capture_kwargs()):
                 opt_step()
         with torch.no_grad():                 # capture does not execute, but be explicit about the state we start from
             self._stats.zero_(); self._off.zero_()
         self._built_for = (id(storage), n, m)
+
+    def _collective_is_capturable(self, dev):
+        """True on every rank or on none: the backend is nccl (RCCL), and a probe graph holding one all_reduce(sum) gives the right
+        sum at two replays with different inputs (a collective that ran at capture time only would return stale data)."""
+        import os
+        import torch.distributed as dist
+        ok = D.backend() == "nccl" and os.environ.get("SOLORL_SPLIT_ALLREDUCE", "0") == "0"
+        if ok:
+            try:
+                probe = torch.zeros(256, device=dev)
+                dist.all_reduce(probe)                                   # communicator set up outside the capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **capture_kwargs()):
+                    dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+                w, r = D.world(), D.rank()
+                for k in (1.0, 3.0):
+                    probe.fill_(k * (r + 1))
+                    g.replay()
+                    torch.cuda.synchronize()
+                    ok = ok and bool((probe == k * w * (w + 1) / 2).all().item())
+            except Exception:
+                ok = False
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                      # (eager; every rank reaches this line)
+        return bool(flag.item())
 
     def update(self, storage):
         if not storage.rewards.is_cuda:
@@ -231,7 +271,7 @@ class GraphedPPO(PPO):
             for _s in range(0, n - m + 1, m):
                 self._g1.replay()
                 if self._split:
-                    self.bucket.all_reduce_mean()
+                    self._reduce()
                     self._g2.replay()
                 n_updates += 1
         if self._mb is not None:

@@ -215,6 +215,12 @@ class SoloVecEnv:
     def increment_curriculum(self, value=1.0):
         _native.check(self.L.solorl_increment_curriculum(self._h, float(value)))
 
+    def get_property(self, name):
+        """Read-only handle properties (include/solorl.h solorl_get_property): lanes_per_env, sweep_variant, max_contacts, ..."""
+        v = C.c_double()
+        _native.check(self.L.solorl_get_property(self._h, name.encode(), C.byref(v)))
+        return v.value
+
     def get_state(self, i=0):
         s = EnvState()
         _native.check(self.L.solorl_get_state(self._h, int(i), C.byref(s)))

@@ -59,19 +59,26 @@ def _worker(rank, world, port, out):
     el = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     m, s = D.global_mean_std(shard(full, rank, world).returns[:-1])
+    # identical replicas after the update: every rank's weights equal rank 0's, bit for bit
+    for p in pol.parameters():
+        ref = p.detach().clone(); dist.broadcast(ref, 0)
+        assert torch.equal(ref, p.detach())
     if rank == 0:
         torch.save(dict(state=pol.state_dict(), losses=losses, el=float(el), mean=float(m), std=float(s)), out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_w_ranks_equal_one_process(tmp_path, world):
+    """world 2 and world 8 (the node size of BASELINE configs 4-5; gloo, one env per rank at 8): W ranks holding 1/W of the rollout each
+    produce the update one process computes from all of it -- no deadlock, identical replicas."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = torch.load(out, weights_only=False)
-    assert got["el"] == 2.0
+    assert got["el"] == float(world)
     full = make_storage(5, N)
     assert got["mean"] == pytest.approx(float(full.returns[:-1].mean()), rel=1e-5)
     assert got["std"] == pytest.approx(float(full.returns[:-1].std()), rel=1e-5)

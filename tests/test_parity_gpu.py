@@ -17,7 +17,7 @@ import torch
 
 from solorl_amd.config import (default_config, ROBOT_SOLO8, ROBOT_SOLO12, TASK_STAND, TASK_WALK, TASK_POINTGOAL,
                                CONTROL_PD, CONTROL_TORQUE)
-from tests.util import GOLDEN, load_state
+from tests.util import GOLDEN, load_state, check_parity_stats
 from tests.golden.make_golden import stand_cfg, stand_action
 
 pytestmark = pytest.mark.gpu
@@ -109,6 +109,7 @@ def test_step_matches_oracle_resynced(gpu_device, robot, task, control):
         t_info = infos.tensors
         assert np.array_equal(t_info["episode_length"].cpu().numpy()[ok], oinfo["episode_length"][ok])
     dq_all = np.array(dq_all)
+    check_parity_stats("step_resynced/robot%d_task%d_control%d" % (robot, task, control), dq_all)
     assert np.median(dq_all) < 1e-4, np.median(dq_all)
     assert np.percentile(dq_all, 90) < 1e-3 + 5e-3 * (control == CONTROL_PD), np.percentile(dq_all, 90)
     assert np.median(dr_all) < 1e-3 and np.median(dobs_all) < 1e-3
@@ -250,6 +251,7 @@ def test_fp64_engine_matches_oracle_tightly(gpu_device):
             assert sg.contact_mask == so.contact_mask
             errs.append(np.abs(np.array(sg.q) - np.array(so.q)).max())
     errs = np.array(errs)
+    check_parity_stats("fp64_engine_resynced", errs, floor=1e-13)
     assert np.median(errs) < 1e-11 and np.percentile(errs, 90) < 1e-7
 
 
@@ -358,6 +360,7 @@ def test_ragged_batch_sizes(gpu_device, n):
         orc.step(a.astype(np.float64))
         assert o.shape == (n, c.obs_dim) and torch.isfinite(o).all()
         dq += [np.abs(np.array(env.get_state(i).q) - np.array(orc.get_state(i).q)).max() for i in range(n)]
+    check_parity_stats("ragged_batch_n%d" % n, dq)
     assert np.median(dq) < 1e-4 and np.max(dq) < 5e-2
 
 

@@ -18,7 +18,7 @@ import torch
 
 from solorl_amd.config import (default_config, config_from_dict, load_yaml, ROBOT_SOLO8, ROBOT_SOLO12, TASK_WALK,
                                TASK_POINTGOAL, CONTROL_PD, PRECISION_F64, EPSTAT_NAMES)
-from tests.util import GOLDEN
+from tests.util import check_parity_stats, GOLDEN
 from tests.golden.make_golden import walk_cfg, walk_action, divergence_horizon
 from tests.test_parity_gpu import make, obs_diff, cfg_for
 
@@ -68,6 +68,7 @@ def test_config5_pd_path_resynced_vs_oracle(gpu_device):
             assert obs_diff(obs.cpu().numpy(), oobs, c.state_dim)[done != 0].max() < 2e-3     # post-reset observations of the envs that ended
     dq = np.array(dq)
     assert timeouts >= 0.4 * N
+    check_parity_stats("config5_pd_path", dq)
     assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 6e-3, (np.median(dq), np.percentile(dq, 90))
     assert np.median(drew) < 1e-3 and np.median(dobs) < 1e-3
 
@@ -310,6 +311,7 @@ def test_treadmill_configs_basic_yaml_vs_oracle(gpu_device):
             mism += sg.contact_mask != so.contact_mask
             strip_seen += (sg.contact_mask >> 24) != 0
     dq = np.array(dq)
+    check_parity_stats("treadmill_basic_yaml", dq)
     assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 1e-3, (np.median(dq), np.percentile(dq, 90))
     assert mism <= 0.02 * len(dq) and strip_seen > 0.3 * len(dq)
     # the strip matters: the same rollout without it separates from this one
@@ -438,6 +440,7 @@ def test_residual_threshold_early_exit_vs_oracle(gpu_device, team):
     dq, its = np.array(dq), np.array(its)
     print("early exit (%s mode): median |dq| %.1e, p90 %.1e; oracle sweeps per solve: median %d, %.0f %% below 50" % (
         "team" if team else "lane", np.median(dq), np.percentile(dq, 90), np.median(its), 100 * (its < 50).mean()))
+    check_parity_stats("residual_exit_%s" % ("team" if team else "lane"), dq)
     assert np.median(its) < 20 and (its < 50).mean() > 0.6
     assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 2e-3, (np.median(dq), np.percentile(dq, 90))
     assert mism <= 0.02 * len(dq)

@@ -399,3 +399,26 @@ def test_policy_kernels_notice_a_reallocated_parameter(gpu_device):
     pol.pi_dist.logstd.data = pol.pi_dist.logstd.data.clone()
     with pytest.raises(RuntimeError, match="moved"):
         policy_act(P, obs, None, v, a, l)
+
+
+def test_config1_shape_64_envs_stand_ppo_smoke(gpu_device, tmp_path):
+    """BASELINE config 1's shape on the HIP path: configs/basic.yaml (Solo8, treadmill, history 1: obs 60, act 8) with the task
+    overridden to 'stand', 64 envs (16 team-mode wavefronts), PPO plumbing end to end: rollout graph, GAE, kernel-path update
+    (mini-batch 512 rows), checkpoint keys."""
+    from solorl_amd.config import load_yaml
+    from solorl_amd.ppo.train import train
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = load_yaml(os.path.join(root, "configs", "basic.yaml"))
+    config["task"] = "stand"
+    args = types.SimpleNamespace(
+        num_agents=64, hidden_size=64, cuda=True, gamma=0.99, tau=0.95, clip_param=0.1, ppo_epoch=5, mini_batch_size=512,
+        lr=2.5e-4, l2_coef=0.0, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5, use_linear_lr_decay=True,
+        use_gae=True, num_env_steps=64 * 64 * 4, seed=1, curriculum_schedule=0, log_interval=1, logdir=str(tmp_path),
+        base_checkpoint=None, save_interval=1, num_steps=64)
+    pol, hist = train(args, config)
+    assert len(hist) == 4 and all(h["fps"] > 0 and h["episodes"] > 0 for h in hist)
+    assert pol.base.features[0].in_features == 60 and pol.pi_dist.mean.out_features == 8
+    assert all(torch.isfinite(p).all() for p in pol.parameters())
+    assert all(abs(h["value_loss"]) < 1e3 and 1.0 < h["entropy"] < 1.6 for h in hist)
+    ck = torch.load(os.path.join(str(tmp_path), "solo.pt"), weights_only=False)
+    assert set(ck.keys()) == {"update", "state_dict", "ob_rms"}
