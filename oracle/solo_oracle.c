@@ -35,6 +35,7 @@
  * restores it for the measurement in tests/test_oracle_caps.py.) */
 static double LIMIT_WINDOW = 0.0;
 #define DISC_EPS2 1e-12
+#define DISC_RIM 0.1     /* sine of the tilt at which a thick disc rests fully on its face (see prim_point) */
 
 /* ------------------------------------------------------------------ small algebra */
 static void v3set(double* a, double x, double y, double z) { a[0] = x; a[1] = y; a[2] = z; }
@@ -274,9 +275,15 @@ static double prim_point(const oracle_env* E, const kin_t* K, int p, double* P) 
     double up[3] = {0, 0, 1}, d[3];
     m3tmulv(d, K->R[l], up);
     for (int k = 0; k < 3; k++) d[k] = -d[k];           /* world down in link axes */
+    const double da = d[pr->axis];                       /* world down along the disc axis: 0 upright, +-1 lying on a face */
     d[pr->axis] = 0;                                     /* project off the disc axis */
     double inv = pr->radius / sqrt(v3dot(d, d) + DISC_EPS2);
     v3axpy(loc, inv, d);
+    /* K6, round 3: the disc has a thickness (a cylinder with rounded rims): its lowest point moves from the mid-plane towards the face
+     * that points down, reaching the face at a tilt of asin(DISC_RIM) -- so a link lying on its side rests half a thickness lower
+     * than its mid-plane, as its hull does, while an upright leg keeps ONE smooth contact point (a sharp rim would make the point
+     * jump by the full thickness whenever the roll changes sign) */
+    if (pr->halfw > 0) { double w = da / DISC_RIM; w = w > 1 ? 1 : (w < -1 ? -1 : w); loc[pr->axis] += pr->halfw * w; }
   }
   m3mulv(P, K->R[l], loc); v3add(P, P, K->o[l]);
   return P[2];

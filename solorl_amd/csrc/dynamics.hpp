@@ -44,6 +44,7 @@ constexpr int NPRIM = 24;                                // 12 base points, knee
 // compete for the rows ten times as often (1.2-2.5 % of random-policy env-steps had more than two candidates, now 0.05-0.17 %).
 constexpr double LIMIT_WINDOW = 0.0;
 constexpr double DISC_EPS2 = 1e-12;
+constexpr double DISC_RIM = 0.1;                         // sine of the tilt at which a thick disc rests fully on its face (disc_point)
 
 // dev builds (-DSOLO_WAVE_TIMING, tools/dev/wave_hist.py): four time stamps per wavefront, kept in registers and written with
 // plain stores at the very end (no atomics, nothing on the sub-steps' path): [workgroup][0] kernel start -> first sub-step,
@@ -214,11 +215,16 @@ template <typename T> SD V3<T> addc(V3<T> o, const M3<T>& R, double x, double y,
   return o;
 }
 
-// support point (relative to the common origin) of a disc with axis y of the link axes R, centre C
-template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius) {
+// support point (relative to the common origin) of a disc with axis y of the link axes R, centre C, half-thickness halfw (K6, round 3:
+// a cylinder with rounded rims -- the lowest point moves from the mid-plane towards the face that points down and reaches it at a tilt
+// of asin(DISC_RIM), so a link lying on its side rests half a thickness lower, as its hull does; oracle: prim_point)
+template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius, T halfw = T(0)) {
   T dx = -R.c0.z, dz = -R.c2.z;                       // world-down expressed in the link's x,z
   T s = radius / sqrt(dx * dx + dz * dz + T(DISC_EPS2));
-  return C + R.c0 * (dx * s) + R.c2 * (dz * s);
+  V3<T> P = C + R.c0 * (dx * s) + R.c2 * (dz * s);
+  T w = -R.c1.z * T(1.0 / DISC_RIM);                  // world-down along the axis, in rim units
+  w = w > T(1) ? T(1) : (w < T(-1) ? T(-1) : w);
+  return P + R.c1 * (halfw * w);
 }
 // the same for a disc about the link's x axis (shoulder housings)
 template <typename T> SD V3<T> disc_point_x(const M3<T>& R, V3<T> C, T radius) {
@@ -288,14 +294,14 @@ SD void leg_prim_points(const M3<T>& R0, const T* sn, const T* cs, V3<T>& kneeP,
     if constexpr (k == NJ - 2) {  // knee disc sits on the upper leg
       constexpr solorl_prim_data PR = RB::MD.prims[12 + 2 * L];
       static_assert(PR.link == L0 + k && PR.axis == 1, "knee primitive layout");
-      kneeP = disc_point(R, addc(o, R, PR.center[0], PR.center[1], PR.center[2]), T(PR.radius));
+      kneeP = disc_point(R, addc(o, R, PR.center[0], PR.center[1], PR.center[2]), T(PR.radius), T(PR.halfw));
     }
     if constexpr (k == NJ - 1) {  // foot: fixed child of the last link
       constexpr solorl_link_data FT = RB::MD.links[L0 + NJ];
       constexpr solorl_prim_data PR = RB::MD.prims[13 + 2 * L];
       static_assert(FT.jtype == 1 && PR.link == L0 + NJ && PR.axis == 1 && PR.center[0] == 0.0 && PR.center[1] == 0.0 &&
                     PR.center[2] == 0.0, "foot primitive layout");
-      footP = disc_point(R, addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]), T(PR.radius));
+      footP = disc_point(R, addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]), T(PR.radius), T(PR.halfw));
     }
   });
 }
@@ -1165,9 +1171,9 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
       if constexpr (RB::SHOULDER && k == 0)   // shoulder housing: disc about x on the HAA link (Solo12)
         shP = disc_point_x(R, o + mul(R, mk(SHC(center[0]), SHC(center[1]), SHC(center[2]))), SHC(radius));
       if constexpr (k == NJ - 2)   // knee disc sits on the upper leg
-        kneeP = disc_point(R, o + mul(R, mk(PRIMC(0, center[0]), PRIMC(0, center[1]), PRIMC(0, center[2]))), PRIMC(0, radius));
+        kneeP = disc_point(R, o + mul(R, mk(PRIMC(0, center[0]), PRIMC(0, center[1]), PRIMC(0, center[2]))), PRIMC(0, radius), PRIMC(0, halfw));
       if constexpr (k == NJ - 1)   // foot: fixed child of the last link, primitive centred on its origin
-        footP = disc_point(R, o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2]))), PRIMC(1, radius));
+        footP = disc_point(R, o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2]))), PRIMC(1, radius), PRIMC(1, halfw));
       Rp = R; op = o;
     });
     C.kneeP[L] = kneeP; C.footP[L] = footP;

@@ -80,7 +80,8 @@ def test_c_header_equals_the_json_table(robot, symbol):
         assert np.allclose(axis, j["axis"]) and np.allclose(jorigin, j["jorigin"], atol=1e-12) and np.allclose(com, j["com"], atol=1e-12)
         assert mass == pytest.approx(j["mass"]) and np.allclose(box, j["inertia_box"], rtol=1e-9) and np.allclose(urdf, j["inertia_urdf"])
     for h, j in zip(prims, m["prims"]):
-        link, axis, center, radius, friction, margin = h
+        link, axis, center, radius, friction, margin, halfw = h
+        assert halfw == pytest.approx(j["halfw"], rel=1e-9) and (halfw > 0) == (axis == 1)      # thick discs: knees and feet (K6, round 3)
         assert link == j["link"] and np.allclose(center, j["center"], atol=1e-9) and radius == pytest.approx(j["radius"], abs=1e-7)
         assert friction == j["friction"] and margin == pytest.approx(j["margin"], rel=1e-6)
     assert [prims[p][0] for p in foot_prim] == m["foot_links"]        # the feet sensor reads the foot primitives

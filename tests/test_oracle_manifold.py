@@ -55,11 +55,11 @@ def _rollout(robot, n, model, seed, N=192, T=200):
 
 
 def test_manifold_vs_primitive_model_measured_gap():
-    """Measured (512 envs x 300 random-policy steps, 3 seeds): Solo12 terminations 6330 +- 20 with the
-    primitives, 5400 +- 15 with hull manifolds (-15 %: lower legs -8 %, upper legs -5 %, feet -4 %, base -2 %, shoulder housings 0 --
-    links lying on their SIDE touch with hull faces the discs do not have), mean base height -8 %, contact points per env 1.2 -> 2.1;
-    Solo8 +3 % / +3 %.  This smaller sample keeps the sign and the size of that gap under test."""
+    """Measured (512 envs x 300 random-policy steps, 3 seeds): Solo12 terminations 5860 +- 30 with the primitives
+    (6330 with the zero-thickness discs of rounds 1-2), 5400 +- 15 with hull manifolds: a gap of -8 % (-15 % before the discs got their
+    thickness; by link class then: lower legs -8 %, upper legs -5 %, feet -4 %, base -2 %, shoulder housings 0), mean base height -4 %,
+    contact points per env 1.3 -> 2.1; Solo8 +1.5 %.  This smaller sample keeps the sign and the size of that gap under test."""
     t0, z0, p0 = _rollout(ROBOT_SOLO12, 12, 0, 1)
     t1, z1, p1 = _rollout(ROBOT_SOLO12, 12, 1, 1)
     print("Solo12: terminations %d -> %d (%+.1f %%), mean base height %.4f -> %.4f, contact points %.2f -> %.2f" % (t0, t1, 100.0 * (t1 - t0) / t0, z0, z1, p0, p1))
-    assert -0.25 < (t1 - t0) / t0 < -0.07 and 1.3 < p1 / p0 < 2.5 and 0.85 < z1 / z0 < 0.99
+    assert -0.16 < (t1 - t0) / t0 < -0.03 and 1.3 < p1 / p0 < 2.5 and 0.90 < z1 / z0 < 0.995

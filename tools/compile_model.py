@@ -138,10 +138,13 @@ def compile_robot(desc_dir, urdf_name):
         ml = hl[:, 2] > kfe[2] - 0.03
         ys = np.concatenate([hu[m, 1], hl[ml, 1]])
         yc = 0.5 * (ys.min() + ys.max())
-        prims.append(dict(link=up, kind="disc", center=[0.0, float(yc), float(kfe[2])], axis=1, radius=r_knee))
+        # halfw: half-thickness of the disc along its axis (round 3, K6): a leg lying on its SIDE rests on the housing's face, half a
+        # thickness below the disc's plane -- the zero-thickness discs of rounds 1-2 let lying legs sink 8-19 mm deeper than their hulls
+        prims.append(dict(link=up, kind="disc", center=[0.0, float(yc), float(kfe[2])], axis=1, radius=r_knee,
+                          halfw=float(0.5 * (ys.max() - ys.min()))))
         hf = hulls[leg + "_FOOT"]
-        prims.append(dict(link=foot, kind="disc", center=[0.0, 0.0, 0.0], axis=1,
-                          radius=float(np.hypot(hf[:, 0], hf[:, 2]).max())))
+        prims.append(dict(link=foot, kind="disc", center=[0.0, float(0.5 * (hf[:, 1].min() + hf[:, 1].max())), 0.0], axis=1,
+                          radius=float(np.hypot(hf[:, 0], hf[:, 2]).max()), halfw=float(0.5 * (hf[:, 1].max() - hf[:, 1].min()))))
     # Solo12 shoulder housings (K6, measured in tests/test_oracle_k6.py: -3 % terminations without them): one disc about the
     # link's x axis (= the HAA axis direction).  The hull's support function in the directions perpendicular to x,
     # h(theta) = max_v (v_y cos theta + v_z sin theta), is fitted by a circle yc cos + zc sin + r in the least-squares
@@ -161,6 +164,7 @@ def compile_robot(desc_dir, urdf_name):
         clean = lambda v: 0.0 if abs(v) < 1e-9 else round(float(v), 9)     # (the four legs' fits then mirror exactly)
         prims.append(dict(link=index[name], kind="disc", center=[clean(xw), clean(yc), clean(zc)], axis=0, radius=clean(r)))
     for p in prims:
+        p.setdefault("halfw", 0.0)
         p["friction"] = links[p["link"]]["friction"] * 1.0   # x plane.urdf lateral friction 1.0 [K6]
         p["margin"] = links[p["link"]]["margin"]
 
@@ -198,7 +202,7 @@ def emit_header(models, path):
     o.append("} solorl_link_data;")
     o.append("typedef struct solorl_prim_data {")
     o.append("  int link; int axis; /* -1 point, 0/1/2 disc axis */ double center[3]; double radius;")
-    o.append("  double friction; double margin;")
+    o.append("  double friction; double margin; double halfw; /* half-thickness of a disc along its axis */")
     o.append("} solorl_prim_data;")
     o.append("typedef struct solorl_model_data {")
     o.append("  const char* name; int nlinks; int ndof; int nprims; int foot_prim[4];")
@@ -219,8 +223,8 @@ def emit_header(models, path):
         o.append("  },")
         o.append("  {")
         for p in m["prims"]:
-            o.append("    {%d, %d, %s, %.17g, %.17g, %.17g}," % (
-                p["link"], p["axis"], c_array(p["center"]), p["radius"], p["friction"], p["margin"]))
+            o.append("    {%d, %d, %s, %.17g, %.17g, %.17g, %.17g}," % (
+                p["link"], p["axis"], c_array(p["center"]), p["radius"], p["friction"], p["margin"], p["halfw"]))
         o.append("  }")
         o.append("};")
     o.append("#endif")
