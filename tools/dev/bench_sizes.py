@@ -13,7 +13,7 @@ for N in sizes:
     amp = 1.0
     if which == "pd50":
         c.control = CONTROL_PD; c.episode_length = 50; amp = 0.3
-    c.solver_residual_threshold = float(os.environ.get("BENCH_THR", "0"))      # K7 early exit (opt-in)
+    if "BENCH_THR" in os.environ: c.solver_residual_threshold = float(os.environ["BENCH_THR"])      # (default: PyBullet's 1e-7)
     env = SoloVecEnv(c, N, device="cuda:0", seed=1); env.reset()
     g = torch.Generator(device="cuda:0"); g.manual_seed(1234)
     a = (torch.rand(64, N, 12, device="cuda:0", generator=g) * 2 - 1) * amp

@@ -2,7 +2,7 @@
 # PMC passes over tools/dev/prof_step.py (steady state, last 40 full-size dispatches), one counter group per pass.
 # usage: pmc_round.sh <tag>
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/${T}_counters_list.txt 2>&1
 pass() { tag=$1; shift; rocprofv3 --pmc "$@" -d $O/${T}_pmc_$tag -o p -- python3 $R/tools/dev/prof_step.py > $O/${T}_pmc_$tag.log 2>&1 && \
