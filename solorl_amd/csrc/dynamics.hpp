@@ -81,6 +81,20 @@ template <> struct Robot<1> {
   static constexpr const solorl_model_data& MD = SOLORL_MODEL_SOLO12;
 };
 
+// the twelve base primitives as sign patterns of prims[0] and prims[8] (phase_front_team computes them from the lane index)
+constexpr bool base_points_are_sign_patterns(const solorl_model_data& md) {
+  const solorl_prim_data& a = md.prims[0]; const solorl_prim_data& b = md.prims[8];
+  for (int p = 0; p < 12; p++) {
+    const solorl_prim_data& q = md.prims[p];
+    const bool plate = p >= 8;
+    const double sx = ((plate ? (p - 8) >> 1 : p >> 2) & 1) ? -1.0 : 1.0, sy = ((plate ? (p - 8) : p >> 1) & 1) ? -1.0 : 1.0;
+    const double cx = (plate ? b.center[0] : a.center[0]) * sx, cy = (plate ? b.center[1] : a.center[1]) * sy;
+    const double cz = plate ? b.center[2] : ((p & 1) ? -a.center[2] : a.center[2]);
+    if (q.link != 0 || q.axis != -1 || q.center[0] != cx || q.center[1] != cy || q.center[2] != cz || q.margin != a.margin || q.friction != a.friction) return false;
+  }
+  return true;
+}
+
 // physics parameters (uniform for the launch)
 template <typename T> struct PhysParams {
   T dt, gravity, erp, slop, warm, damping, vmax, qlim, inv_dt;
@@ -441,7 +455,7 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     if (lpen[2 * j + 1] <= T(LIMIT_WINDOW)) lcand |= 1 << (2 * j + 1);
   }
   int lsel = lcand;
-  if (__popc(lcand) > MAX_LIMITS) {
+  if (__builtin_popcount(lcand) > MAX_LIMITS) {
     lsel = 0;                          // (statically indexed: a rolled loop would put lpen[] in scratch for every lane, every sub-step)
     static_for<2 * NQ>([&](auto ac) {
       constexpr int a = decltype(ac)::value;
@@ -453,8 +467,8 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
       if (((lcand >> a) & 1) && rank < MAX_LIMITS) lsel |= 1 << a;
     });
   }
-  const int capc = contact_cap(__popc(lsel));
-  if (__popc(mask) > capc) {   // keep the deepest (ties: lower primitive id)
+  const int capc = contact_cap(__builtin_popcount(lsel));
+  if (__builtin_popcount(mask) > capc) {   // keep the deepest (ties: lower primitive id)
     int keep = 0;
     static_for<NPRIM>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
@@ -467,7 +481,7 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     });
     mask = keep;
   }
-  C.mask = mask; C.nc = __popc(mask); C.nlim_total = __popc(lsel); C.lsel = lsel;
+  C.mask = mask; C.nc = __builtin_popcount(mask); C.nlim_total = __builtin_popcount(lsel); C.lsel = lsel;
   C.smask = smask & mask;
   // base link terms start the articulated-inertia accumulation
   constexpr solorl_link_data B = RB::MD.links[0];
@@ -592,7 +606,7 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
         T sg = side == 0 ? T(1) : T(-1);
         T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
         JL[k] = sg;
-        park_row(lds, __popc(lsel & ((1 << bit) - 1)), LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
+        park_row(lds, __builtin_popcount(lsel & ((1 << bit) - 1)), LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
       }
     }
   });
@@ -604,7 +618,7 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
     constexpr int DEPTH = i == 0 ? NJ - 1 : (i == 1 ? NJ : 1);
     constexpr solorl_prim_data PR = RB::MD.prims[p];
     if ((mask >> p) & 1) {
-      const int cidx = __popc(mask & ((1 << p) - 1));
+      const int cidx = __builtin_popcount(mask & ((1 << p) - 1));
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
       const V3<T> P = i == 0 ? C.kneeP[L] : (i == 1 ? C.footP[L] : C.shP[L]);
       const T pen = C.dist[p] + pp.slop;
@@ -776,7 +790,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
           T sg = side == 0 ? T(1) : T(-1);
           T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
           JL[k] = sg;
-          park_row(lds, __popc(lsel & ((1 << bit) - 1)), LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
+          park_row(lds, __builtin_popcount(lsel & ((1 << bit) - 1)), LR.G[k] * (-sg), JL, Y, mk(T(0), T(0), T(0)), pen, T(0), T(0), (L << 5) | (3 << 8));
         }
       }
     });
@@ -789,7 +803,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
     constexpr int P0 = i < 2 ? 12 + i : 20, PS = i < 2 ? 2 : 1;        // this primitive of leg L: P0 + PS * L
     const int p = P0 + PS * L;
     if ((mask >> p) & 1) {
-      const int cidx = __popc(mask & ((1 << p) - 1));
+      const int cidx = __builtin_popcount(mask & ((1 << p) - 1));
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
       const V3<T> P = i == 0 ? C.kneeP[L] : (i == 1 ? C.footP[L] : C.shP[L]);
       const T pen = C.dist[p] + pp.slop;
@@ -834,7 +848,7 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, const T* lam_pre
       constexpr int p = decltype(pc)::value;
       constexpr solorl_prim_data PR = RB::MD.prims[p];
       if ((mask >> p) & 1) {
-        const int cidx = __popc(mask & ((1 << p) - 1));
+        const int cidx = __builtin_popcount(mask & ((1 << p) - 1));
         const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
         const V3<T> P = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
         const T lam0 = pp.warm * (TEAMQ ? C.lamp[p] : lam_prev[(unsigned)p * nstride]);
@@ -1028,7 +1042,7 @@ SNI void phase_pgs(CH ch, int iterations, T resid_thr, const LDS lds) {
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     const int p = 12 + i;
-    C.lam_n[i] = ((C.mask >> p) & 1) ? lds.A(nlt + __popc(C.mask & ((1 << p) - 1)), R_::A_LAM) : T(0);
+    C.lam_n[i] = ((C.mask >> p) & 1) ? lds.A(nlt + __builtin_popcount(C.mask & ((1 << p) - 1)), R_::A_LAM) : T(0);
   }
 }
 
@@ -1045,7 +1059,7 @@ SNI void phase_integrate(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned ns
     constexpr int p = decltype(pc)::value;
     T l = T(0);
     if constexpr (p < 12) {
-      if ((mask >> p) & 1) l = lds.A(nlt + __popc(mask & ((1 << p) - 1)), LDS::A_LAM);
+      if ((mask >> p) & 1) l = lds.A(nlt + __builtin_popcount(mask & ((1 << p) - 1)), LDS::A_LAM);
     } else l = C.lam_n[p - 12];
     lam_prev[(unsigned)p * nstride] = l;
   });
@@ -1196,14 +1210,18 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
 #undef PRIMC
 #undef LEGC
   } else if (valid) {
-    const int p = t - 4;     // base point p: centre, margin, friction picked from the twelve compile-time values
-    T cx = T(0), cy = T(0), cz = T(0), mg = T(0);
-    static_for<12>([&](auto pc) {
-      constexpr int q = decltype(pc)::value;
-      constexpr solorl_prim_data PR = RB::MD.prims[q];
-      static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
-      if (p == q) { cx = T(PR.center[0]); cy = T(PR.center[1]); cz = T(PR.center[2]); mg = T(PR.margin); bfric = T(PR.friction); }
-    });
+    const int p = t - 4;     // base point p: the twelve points are sign patterns of two corner points (8 box-diagonal extremes of the
+    // hull, prims 0..7 = (sx, sy, sz) with p = 4 [sx < 0] + 2 [sy < 0] + [sz > 0]; 4 belly-plate corners, prims 8..11 = (sx, sy) with
+    // p - 8 = 2 [sx < 0] + [sy < 0]) and share margin and friction: arithmetic on the lane index instead of a 12-way select (which the
+    // compiler turned into a tree of ~40 exec-mask branches on the path of every sub-step)
+    constexpr solorl_prim_data PA = RB::MD.prims[0], PB = RB::MD.prims[8];
+    static_assert(base_points_are_sign_patterns(RB::MD), "base primitive table layout (tools/compile_model.py)");
+    const bool plate = p >= 8;
+    const T sgx = ((plate ? p >> 1 : p >> 2) & 1) ? T(-1) : T(1), sgy = ((plate ? p : p >> 1) & 1) ? T(-1) : T(1);
+    const T cx = (plate ? T(PB.center[0]) : T(PA.center[0])) * sgx, cy = (plate ? T(PB.center[1]) : T(PA.center[1])) * sgy;
+    const T cz = plate ? T(PB.center[2]) : ((p & 1) ? T(-PA.center[2]) : T(PA.center[2]));
+    const T mg = T(PA.margin);
+    bfric = T(PA.friction);
     bP = mul(R0, mk(cx, cy, cz));
     bdist = pz + bP.z;
     C.dist[p] = bdist;
@@ -1217,7 +1235,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   int mask = team_or16(bits);
   lbits = team_or16(lbits);
-  if (__popc(lbits) > MAX_LIMITS) {
+  if (__builtin_popcount(lbits) > MAX_LIMITS) {
     // more joints at their limits than limit rows (MAX_LIMITS): the smallest margins, i.e. the most violated, win
     // (ties: lower joint, lower side) -- same rule as phase_detect, see there.  Lane t ranks its own joint's two sides against
     // the team's margins in LDS.
@@ -1241,8 +1259,8 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     lbits = team_or16(sel);
   }
   if (pp.tm_on) sbits = team_or16(sbits);     // (uniform branch)
-  const int capc = contact_cap(__popc(lbits));   // limit rows 3 and 4 take the place of contact points (see MAX_LIMITS)
-  if (__popc(mask) > capc) {
+  const int capc = contact_cap(__builtin_popcount(lbits));   // limit rows 3 and 4 take the place of contact points (see MAX_LIMITS)
+  if (__builtin_popcount(mask) > capc) {
     // more primitives touch than there are contact slots (a robot lying on the ground -- the heaviest wavefronts, which set the launch
     // time): keep the deepest, ties to the lower id.  Lane t ranks primitives t and t+16 against the team's distances in LDS
     // (the serial version on the leader was a 1 900-instruction non-inlined call that also made this phase save registers on
@@ -1262,10 +1280,10 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     }
     mask = team_or16(keep);
   }
-  const int nl = __popc(lbits);
+  const int nl = __builtin_popcount(lbits);
   if (valid && t >= 4 && ((mask >> (t - 4)) & 1)) {    // base contacts: every touching point parks its own three rows
-    const int p = t - 4, nlt = nl, nc = __popc(mask);
-    const int cidx = __popc(mask & ((1 << p) - 1));
+    const int p = t - 4, nlt = nl, nc = __builtin_popcount(mask);
+    const int cidx = __builtin_popcount(mask & ((1 << p) - 1));
     const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
     const T lam0 = pp.warm * C.lamp[p];
     const T Z[3] = {T(0), T(0), T(0)};
@@ -1278,7 +1296,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
   }
   if (!lead) return;
   C.R0 = R0;
-  C.mask = mask; C.nc = __popc(mask); C.nlim_total = nl; C.lsel = lbits;
+  C.mask = mask; C.nc = __builtin_popcount(mask); C.nlim_total = nl; C.lsel = lbits;
   C.smask = sbits & mask;
   // base link terms start the articulated-inertia accumulation
   constexpr solorl_link_data B = RB::MD.links[0];
@@ -1670,7 +1688,7 @@ SNI_SCALAR void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev,
   const T* lam = TRW::lam(lds.lane);
   const int npos0 = TRW::NPOS0 + extra_limits(C.nlim_total);
   for (int p = t; p < NPRIM; p += 16) {       // warm-start cache: normal impulse of primitive p (its rank among the contacts)
-    const T l = ((mask >> p) & 1) ? lam[(npos0 + __popc(mask & ((1 << p) - 1))) * 4] : T(0);
+    const T l = ((mask >> p) & 1) ? lam[(npos0 + __builtin_popcount(mask & ((1 << p) - 1))) * 4] : T(0);
     C.lamp[p] = l;
   }
   const T* hdr = lds.hdr();

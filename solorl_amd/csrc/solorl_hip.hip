@@ -71,6 +71,7 @@ struct EnvParams {
   int task, control, frame_skip, episode_length, hold_torque, disable_termination;
   int settle_min, nsettle;
   int use_treadmill; float tm_offset;         // treadmill: side redrawn at reset (simulation.py:72-74)
+  int linear_ids;                             // slot e holds env e (no contact-count sorting): no slot -> env-id load on the step's critical path
   int lds_poison_on; unsigned lds_poison;     // test hook, see step_body
   unsigned seed_lo, seed_hi; long long id0;
   double kp, kd, max_torque, reward_dt;
@@ -477,7 +478,7 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   // ---- the env's state, HBM -> LDS, all lanes (the state is stored by slot: slot e holds env `env`)
   T a_t = T(0);
   if (valid) {
-    env = (idx_t)si[SX(I_ENVID, e, NI)];
+    env = P.linear_ids ? e : (idx_t)si[SX(I_ENVID, e, NI)];      // (the action load below depends on it: one HBM round trip less)
     for (int f = t; f < NPS; f += 16) psv[f] = sf[SX(L.pos + f, e, L.NF)];
     if (t < NER) C.erec[t] = sf[SX(L.goal + t, e, L.NF)];
     if (t < 3) C.irec[t] = si[SX(t, e, NI)];
@@ -975,6 +976,7 @@ EnvParams make_env_params(const solorl_env* h) {
   P.kp = c.kp; P.kd = c.kd; P.max_torque = c.max_torque; P.reward_dt = c.reward_dt; P.dyn = h->dyn;
   P.lds_poison_on = h->lds_poison_on; P.lds_poison = h->lds_poison;
   P.use_treadmill = c.use_treadmill; P.tm_offset = (float)c.treadmill_offset;
+  P.linear_ids = h->sort ? 0 : 1;
   return P;
 }
 template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
