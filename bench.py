@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the fp64-instantiation leg")
+    ap.add_argument("--leg-timeout", type=int, default=420, help="watchdog (s) over the auxiliary legs (PPO loop, fp64, CPU baseline): the headline line is printed without them if they hang")
     ap.add_argument("--ppo-steps", type=int, default=400, help="rollout length of the PPO-loop leg (0 = skip); README: num_steps = episode_length")
     ap.add_argument("--ppo-epoch", type=int, default=5, help="PPO epochs of that leg (README: 5)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -321,40 +322,7 @@ def main(argv=None):
     elapsed, dev_elapsed = walls[mid], devs[mid]
     k_avg = 1e3 * dev_elapsed / K                 # ms per launch inside the timed window (graph: includes the ~1 us node gaps)
 
-    ppo = None
-    if args.ppo_steps > 0:
-        # BASELINE config 3 / 4: the full PPO loop (rollout + GAE + clipped update) on the same engine; never fatal
-        try:
-            ppo = ppo_leg(env, dev, world, args.ppo_steps, args.ppo_epoch)
-        except Exception as ex:     # never fatal for the headline line.  A failure on ONE rank leaves the others inside a collective
-            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}     # of the leg: they time out with the process group (NCCL watchdog),
-        if world > 1 and not all_ranks("error" not in (ppo or {})):   # and every rank that does return agrees on the outcome before
-            ppo = ppo if (ppo and "error" in ppo) else {"error": "the PPO leg failed on another rank"}     # any further collective
-
-    # the same workload on the engine's fp64 instantiation (the reference's arithmetic type), single repeat of <= 100 steps
-    f64 = None
-    if not args.no_f64:
-        try:
-            from solorl_amd.config import PRECISION_F64
-            c64 = cfg.copy(); c64.precision = PRECISION_F64
-            e64 = SoloVecEnv(c64, N, device=dev, seed=1, env_id_offset=rank * N)
-            e64.reset()
-            for t in range(burn_in):
-                e64.step_inplace(acts[t % R])
-            K64 = min(K, 100)
-            barrier(); t0 = time.perf_counter()
-            for t in range(K64):
-                e64.step_inplace(acts[t % R])
-            barrier(); el64 = time.perf_counter() - t0
-            if world > 1:
-                t_ = torch.tensor([el64], device=dev, dtype=torch.float64); dist.all_reduce(t_, op=dist.ReduceOp.MAX); el64 = float(t_.item())
-            f64 = {"value": world * N * K64 / el64, "unit": "env-steps/s", "ms_per_step": 1e3 * el64 / K64, "steps": K64, "dtype": "f64",
-                   "launch": "eager", "note": "step_kernel_team<double,solo12>, same workload and burn-in; parity-tested against the oracle to rounding"}
-            e64.close()
-        except Exception as ex:
-            f64 = {"error": "%s: %s" % (type(ex).__name__, ex)}
-
-    if rank == 0:
+    def build_line(f64, ppo):
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
         bytes_step = algorithmic_bytes_per_env_step(A=A, S=S, C=48, O=O, hist_state=D)
         achieved = bytes_step * N / (k_avg * 1e-3) / 1e9
@@ -407,12 +375,83 @@ def main(argv=None):
             out["f64"] = f64
         if ppo is not None:
             out["ppo_loop"] = ppo
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if state.get("cpu") is not None:
+            out["cpu_baseline"] = state["cpu"]
+        return out
+
+    ppo = None
+    # From here on every leg is auxiliary to the headline measurement above.  A leg that HANGS (e.g. a collective of the PPO leg on a
+    # multi-GPU node) cannot be caught by try/except, so a watchdog guarantees the line: when it fires, rank 0 prints the headline with
+    # the legs finished so far and every rank leaves (os._exit: no collective is waited for).
+    import threading
+    state = {"f64": None, "ppo": {"error": "not run"} if args.ppo_steps > 0 else None, "printed": False}
+
+    def emit(extra_note=None):
+        if state["printed"] or rank != 0:
+            return
+        state["printed"] = True
+        line = build_line(state["f64"], state["ppo"])
+        if extra_note:
+            line["note"] = extra_note
+        print(json.dumps(line), flush=True)
+
+    def on_timeout():
+        if state["ppo"] is not None and state["ppo"].get("error") == "not run":
+            state["ppo"] = {"error": "the PPO leg did not finish within %d s (watchdog); headline unaffected" % args.leg_timeout}
+        emit("auxiliary legs cut short by the watchdog")
+        os._exit(0)
+
+    watchdog = threading.Timer(args.leg_timeout, on_timeout)
+    watchdog.daemon = True
+    watchdog.start()
+    # the same workload on the engine's fp64 instantiation (the reference's arithmetic type), single repeat of <= 100 steps
+    f64 = None
+    if not args.no_f64:
+        try:
+            from solorl_amd.config import PRECISION_F64
+            c64 = cfg.copy(); c64.precision = PRECISION_F64
+            e64 = SoloVecEnv(c64, N, device=dev, seed=1, env_id_offset=rank * N)
+            e64.reset()
+            for t in range(burn_in):
+                e64.step_inplace(acts[t % R])
+            K64 = min(K, 100)
+            barrier(); t0 = time.perf_counter()
+            for t in range(K64):
+                e64.step_inplace(acts[t % R])
+            barrier(); el64 = time.perf_counter() - t0
+            if world > 1:
+                t_ = torch.tensor([el64], device=dev, dtype=torch.float64); dist.all_reduce(t_, op=dist.ReduceOp.MAX); el64 = float(t_.item())
+            f64 = {"value": world * N * K64 / el64, "unit": "env-steps/s", "ms_per_step": 1e3 * el64 / K64, "steps": K64, "dtype": "f64",
+                   "launch": "eager", "note": "step_kernel_team<double,solo12>, same workload and burn-in; parity-tested against the oracle to rounding"}
+            e64.close()
+        except Exception as ex:
+            f64 = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    state["f64"] = f64
+
+    if args.ppo_steps > 0:
+        # BASELINE config 3 / 4: the full PPO loop (rollout + GAE + clipped update) on the same engine; never fatal
+        try:
+            ppo = ppo_leg(env, dev, world, args.ppo_steps, args.ppo_epoch)
+        except Exception as ex:     # never fatal for the headline line.  A failure on ONE rank leaves the others inside a collective
+            ppo = {"error": "%s: %s" % (type(ex).__name__, ex)}     # of the leg: they time out with the process group (NCCL watchdog),
+        if world > 1 and not all_ranks("error" not in (ppo or {})):   # and every rank that does return agrees on the outcome before
+            ppo = ppo if (ppo and "error" in ppo) else {"error": "the PPO leg failed on another rank"}     # any further collective
+    state["ppo"] = ppo
+
+    state["cpu"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        state["cpu"] = cpu_baseline(cfg)
+    watchdog.cancel()
+    emit()
+    if world > 1:                         # the line is out: a rank whose process group is unhealthy must not keep the job from ending
+        bye = threading.Timer(60, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
