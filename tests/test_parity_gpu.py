@@ -59,6 +59,24 @@ def test_engine_library_is_loaded(gpu_device):
     assert "libsolorl_hip.so" in open("/proc/self/maps").read() or "libsolorl_hip.so" in maps
 
 
+def test_handle_properties(gpu_device, monkeypatch):
+    """solorl_get_property: what a handle runs (the sweep variant used to be a silent function of the grid size)."""
+    from solorl_amd import _native
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    env, _ = make(c, 8)
+    assert env.get_property("lanes_per_env") == 16 and env.get_property("max_contacts") == 8 and env.get_property("max_limit_rows") == 4
+    assert env.get_property("sweep_variant") == 2 and env.get_property("f64") == 0          # PyBullet's residual exit: one variant at every size
+    with pytest.raises(_native.SoloRLError):
+        env.get_property("no_such_property")
+    c0 = cfg_for(ROBOT_SOLO12, TASK_WALK, solver_residual_threshold=0.0)
+    small, _ = make(c0, 8)
+    big, _ = make(c0, 8192)
+    assert small.get_property("sweep_variant") == 1 and big.get_property("sweep_variant") == 0   # fixed sweeps: pipelined / plain by grid size
+    monkeypatch.setenv("SOLORL_TEAM", "0")
+    lane, _ = make(c, 8)
+    assert lane.get_property("lanes_per_env") == 1
+
+
 @pytest.mark.parametrize("robot,task", [(ROBOT_SOLO8, TASK_STAND), (ROBOT_SOLO12, TASK_WALK), (ROBOT_SOLO12, TASK_POINTGOAL)])
 def test_reset_matches_oracle(gpu_device, robot, task):
     """reset = snapshot[K] on the GPU vs K live settle steps in the oracle; K and goals from Philox."""
