@@ -24,7 +24,10 @@ def _stale(target, deps):
 
 def _flags():
     # -fno-slp-vectorize: packed fp32 operations appear only where the source writes 2-vectors (the PGS sweep, dynamics.hpp)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include")]
+    # -disable-promote-alloca-to-lds: the step kernels must have NO static LDS -- their phase functions address the dynamic LDS from a
+    #   constant base (dynamics.hpp, SOLO_LDS_BASE); left alone the compiler moved a private array of the fp64 team kernel into 3 KB of it
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm", "-disable-promote-alloca-to-lds",
+             "-I" + os.path.join(ROOT, "include")]
     flags += ["-D" + d for d in os.environ.get("SOLORL_BUILD_DEFINES", "").split() if d]   # dev instrumentation
     flags += os.environ.get("SOLORL_BUILD_FLAGS", "").split()                                 # dev experiments
     return flags

@@ -124,7 +124,23 @@ template <typename T> struct JointF { SV<T> S, U, c; T Dinv, u; };
 // `extern __shared__` symbol so they stay address-space-3 (ds_* instructions) across the
 // non-inlined phase boundaries -- generic pointers would turn every access into a FLAT one.
 #ifndef SOLO_HOST_SHIM
-extern __shared__ __attribute__((aligned(16))) unsigned char solo_smem[];
+extern __shared__ __attribute__((aligned(16))) unsigned char solo_smem_sym[];
+// The step kernels have no static LDS, so their dynamic LDS starts at offset SOLO_LDS_BASE = 0 and every phase function addresses
+// it from that constant.  (Through the `extern __shared__` symbol a NON-kernel function finds the start of the dynamic LDS with a
+// scalar load from a per-kernel table -- an exposed scalar-cache round trip at the top of every phase call, and, since scalar loads
+// return out of order, an s_waitcnt lgkmcnt(0) that drains every LDS read in flight wherever the compiler re-loads it.)
+// Checked where it can be: step_team / step_lane compare the symbol's offset with the constant on entry, and
+// tests/test_abi.py reads the kernels' static LDS size from the code object.
+#if defined(SOLO_WAVE_TIMING)
+constexpr unsigned SOLO_LDS_BASE = 80;                   // behind solo_pt_acc[10]
+#else
+constexpr unsigned SOLO_LDS_BASE = 0;
+#endif
+typedef __attribute__((address_space(3))) unsigned char solo_lds_byte;
+// (written as a non-zero LDS address minus its distance from the base: LDS offset 0 itself would be taken for the null pointer,
+// whose generic counterpart is not LDS offset 0)
+#define solo_smem (((unsigned char*)reinterpret_cast<solo_lds_byte*>(SOLO_LDS_BASE + 4096u)) - 4096)
+SD bool solo_lds_base_ok() { return (unsigned)(size_t)(solo_lds_byte*)solo_smem_sym == SOLO_LDS_BASE; }
 #endif
 #ifdef SOLO_HOST_SHIM
 template <typename T> constexpr int default_lanes() { return 1; }
@@ -1139,8 +1155,15 @@ template <typename T, typename LDS> struct TeamRows {
   SD static int row_of(int pos, int nlt, int nc) {
     const int ne = extra_limits(nlt), nl0 = nlt - ne;
     const int kn = pos - NPOS0, kf = pos - FPOS0 - 2 * ne;
-    return pos < NPOS0 ? (pos < nl0 ? pos : -1)
-                       : (pos < FPOS0 ? (kn < ne ? nl0 + kn : (kn - ne < nc ? nlt + (kn - ne) : -1)) : ((kf >= 0 && kf < 2 * nc) ? nlt + nc + kf : -1));
+    // (selects, not branches: every candidate is computed -- the sweep's set-up evaluates this for 26 positions and a
+    // divergent branch per position cost more than the arithmetic)
+    const int rl = pos < nl0 ? pos : -1;
+    const int a_lim = nl0 + kn, a_con = nlt + (kn - ne), a_fr = nlt + nc + kf;
+    const int rc = (kn - ne < nc) ? a_con : -1;
+    const int rn = kn < ne ? a_lim : rc;
+    const int rf = ((kf >= 0) & (kf < 2 * nc)) ? a_fr : -1;
+    const int rnf = pos < FPOS0 ? rn : rf;
+    return pos < NPOS0 ? rl : rnf;
   }
 };
 
@@ -1331,17 +1354,34 @@ SNI_SCALAR void phase_base_lead(CH ch, const PhysParams<T> pp, const T* lam_prev
   SubCtx<T, ROBOT>& C = ch.get();
   using TRW = TeamRows<T, LDS>;
   constexpr int LN = LDS::LANES;
-  Sym6<T> Lam; SV<T> a0;
-  base_solve<T, ROBOT, LDS, true>(C, pp, lam_prev, nstride, lds, Lam, a0);
+  // the arithmetic of base_solve<TEAMQ = true>, laid out as LOAD everything -> compute -> STORE everything: LDS pointers may alias as
+  // far as the compiler knows, so a read behind a store is a separate round trip (~64 cycles each for a lone wavefront; this phase had a
+  // dozen, five of them reading back the u* it had just stored)
+  const int nlt = C.nlim_total, nc = C.nc;
+  const ABI<T> Ib = C.Ibase;
+  const SV<T> pb = C.pbase;
+  const V3<T> bw = C.ps.w, bv = C.ps.v;
+  const Sym6<T> Lam = spd_inverse_block(Ib);
+  const SV<T> a0 = mul(Lam, pb) * T(-1);
+  const T dt = pp.dt;
+  V3<T> vdot = a0.l + cross(bw, bv); vdot.z -= pp.gravity;      // base acceleration (gravity via the accelerating-frame trick), u* = u + dt*udot
+  SV<T> ub;
+  ub.a = mk(clampv(bw.x + dt * a0.a.x, pp.vmax), clampv(bw.y + dt * a0.a.y, pp.vmax), clampv(bw.z + dt * a0.a.z, pp.vmax));
+  ub.l = mk(clampv(bv.x + dt * vdot.x, pp.vmax), clampv(bv.y + dt * vdot.y, pp.vmax), clampv(bv.z + dt * vdot.z, pp.vmax));
+  if (nlt + 3 * nc == 0) {   // the branch-free PGS sweep touches row 0 of every lane: make it a null row
+    const T Z[3] = {T(0), T(0), T(0)};
+    park_row(lds, 0, zero6<T>(), Z, Z, mk(T(0), T(0), T(0)), T(0), T(0), T(0), 0);
+  }
+  C.ub = ub;
   T* bc = TRW::bc(lds.lane);
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
     for (int j = 0; j < 6; j++) bc[i * 6 + j] = Lam.m[i][j];
-  bc[36] = C.ub.a.x; bc[37] = C.ub.a.y; bc[38] = C.ub.a.z; bc[39] = C.ub.l.x; bc[40] = C.ub.l.y; bc[41] = C.ub.l.z;
+  bc[36] = ub.a.x; bc[37] = ub.a.y; bc[38] = ub.a.z; bc[39] = ub.l.x; bc[40] = ub.l.y; bc[41] = ub.l.z;
   bc[54] = a0.a.x; bc[55] = a0.a.y; bc[56] = a0.a.z; bc[57] = a0.l.x; bc[58] = a0.l.y; bc[59] = a0.l.z;
   T* hdr = lds.hdr();
-  hdr[0] = T(C.nlim_total); hdr[LN] = T(C.nc);
+  hdr[0] = T(nlt); hdr[LN] = T(nc);
 }
 
 // unconstrained leg rates u*_leg = qd + dt (qdd0 - G.a0), clamped: joint t on lane t (padded copy for the rows)
@@ -1510,33 +1550,63 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   T th[EXIT ? n : 1];                            // (K7) |delta| above which a row keeps its team iterating
   T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
   P2 a01 = {T(0), T(0)}; T a2 = T(0);
-  static_for<n>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int k = Ord::slot(i);
-    const int r_own = TRW::row_of(2 * k + half, nlt, nc), r_oth = TRW::row_of(2 * k + 1 - half, nlt, nc);
-    const int ro = r_own < 0 ? 0 : r_own, rx = r_oth < 0 ? 0 : r_oth;        // (a safe row to read; the value is discarded)
-    const int lo = r_own < 0 ? -3 : (int)elem(ro, E_LEG), lx = r_oth < 0 ? -3 : (int)elem(rx, E_LEG);
-    const bool uo = r_own >= 0 && (legU == -1 || legU == lo), vo = legV == lo, wo = legW == lo;
-    const bool ux = r_oth >= 0 && (legU == -1 || legU == lx), vx = legV == lx, wx = legW == lx;
-    const T ju = elem(ro, eU), bu = elem(ro, eU + dJB), jv = elem(ro, eV), bv = elem(ro, eV + dJB), jw = elem(ro, eW), bw = elem(ro, eW + dJB);
-    const T xu = elem(rx, eU + dJB), xv = elem(rx, eV + dJB), xw = elem(rx, eW + dJB);
-    const T rhs = elem(ro, E_RHS);
-    J0[i] = uo ? ju : T(0); J1[i] = vo ? jv : T(0); J2[i] = wo ? jw : T(0);
-    B01[i] = P2{uo ? bu : T(0), vo ? bv : T(0)}; B2[i] = wo ? bw : T(0);
-    X01[i] = P2{ux ? xu : T(0), vx ? xv : T(0)}; X2[i] = wx ? xw : T(0);
-    // rhs' rides in the reduction: every lane of a half starts its partial sum at -rhs'/8 (exact scaling), so the reduced
-    // value is J'.acc - rhs' and the row update needs one subtraction instead of an add and a subtract
-    rh[i] = r_own >= 0 ? rhs * T(-0.125) : T(0);
-    if constexpr (EXIT) th[i] = r_own >= 0 ? lds.A(ro, LDS::A_LAM) : T(0);
-    // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
-    // partner's B~; half 0 takes 0 (its row does not wait for anybody)
-    const T c = team_red8(J0[i] * X01[i].x + J1[i] * X01[i].y + J2[i] * X2[i]);
-    cp[i] = half ? c : T(0);
-    lm[i] = *reinterpret_cast<const T*>(solo_smem + lam_own + 2 * k * S_LAM);
-    // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
-    const T lx_ = half_swap(lm[i]);
-    if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx_;
-    a01 = fm(X01[i], P2{lx_, lx_}, fm(B01[i], P2{lm[i], lm[i]}, a01)); a2 = fm(X2[i], lx_, fm(B2[i], lm[i], a2));
+  // Set-up in two passes.  Pass 1 issues EVERY LDS read of every slot -- unconditionally, from a safe row where the team has none, so that
+  // there is no branch between them -- and pass 2 masks and combines them.  Written slot by slot (round 2) the reads of a slot sat behind
+  // branches and the previous slot's DPP reductions: five to six separate LDS round trips per slot, ~70 per call for a 13-slot sweep --
+  // 1.5 us per sub-step on exactly the wavefronts that set the launch time.
+  int rown[n], roth[n];
+  T lego[n], legx[n];                            // (leg ids as stored: converted in pass 2, a conversion here would wait for its read)
+  T ju[n], bu[n], jv[n], bv[n], jw[n], bw[n], xu[n], xv[n], xw[n], rhs_[n];
+  // In groups of SETUP_GROUP slots (all 13 at once would need ~210 registers for the raw values alone): reads of the group, a compiler
+  // barrier for memory operations, a second one that re-defines the read values (an empty asm with "+v" operands -- without it the
+  // scheduler hoists each slot's arithmetic, which is not a memory operation, back up to its reads and the round trips are per slot again).
+  constexpr int SETUP_GROUP = 5;
+  static_for<(n + SETUP_GROUP - 1) / SETUP_GROUP>([&](auto gc) {
+    constexpr int g0 = decltype(gc)::value * SETUP_GROUP, gn = (n - g0 < SETUP_GROUP ? n - g0 : SETUP_GROUP);
+    static_for<gn>([&](auto jc) {
+      constexpr int i = g0 + decltype(jc)::value;
+      constexpr int k = Ord::slot(i);
+      rown[i] = TRW::row_of(2 * k + half, nlt, nc); roth[i] = TRW::row_of(2 * k + 1 - half, nlt, nc);
+      const int ro = rown[i] < 0 ? 0 : rown[i], rx = roth[i] < 0 ? 0 : roth[i];        // (a safe row to read; the value is discarded)
+      lego[i] = elem(ro, E_LEG); legx[i] = elem(rx, E_LEG);
+      ju[i] = elem(ro, eU); bu[i] = elem(ro, eU + dJB); jv[i] = elem(ro, eV); bv[i] = elem(ro, eV + dJB); jw[i] = elem(ro, eW); bw[i] = elem(ro, eW + dJB);
+      xu[i] = elem(rx, eU + dJB); xv[i] = elem(rx, eV + dJB); xw[i] = elem(rx, eW + dJB);
+      rhs_[i] = elem(ro, E_RHS);
+      if constexpr (EXIT) th[i] = lds.A(ro, LDS::A_LAM);
+      lm[i] = *reinterpret_cast<const T*>(solo_smem + lam_own + 2 * k * S_LAM);
+    });
+#ifndef SOLO_HOST_SHIM
+    asm volatile("" ::: "memory");
+    static_for<gn>([&](auto jc) {
+      constexpr int i = g0 + decltype(jc)::value;
+      asm volatile("" : "+v"(ju[i]), "+v"(bu[i]), "+v"(jv[i]), "+v"(bv[i]), "+v"(jw[i]), "+v"(bw[i]), "+v"(xu[i]), "+v"(xv[i]), "+v"(xw[i]),
+                        "+v"(rhs_[i]), "+v"(lm[i]), "+v"(lego[i]), "+v"(legx[i]));
+      T& thi = th[EXIT ? i : 0];
+      if constexpr (EXIT) asm volatile("" : "+v"(thi));
+    });
+#endif
+    static_for<gn>([&](auto jc) {
+      constexpr int i = g0 + decltype(jc)::value;
+      const int r_own = rown[i], r_oth = roth[i];
+      const int lo = r_own < 0 ? -3 : (int)lego[i], lx = r_oth < 0 ? -3 : (int)legx[i];
+      const bool uo = r_own >= 0 && (legU == -1 || legU == lo), vo = legV == lo, wo = legW == lo;
+      const bool ux = r_oth >= 0 && (legU == -1 || legU == lx), vx = legV == lx, wx = legW == lx;
+      J0[i] = uo ? ju[i] : T(0); J1[i] = vo ? jv[i] : T(0); J2[i] = wo ? jw[i] : T(0);
+      B01[i] = P2{uo ? bu[i] : T(0), vo ? bv[i] : T(0)}; B2[i] = wo ? bw[i] : T(0);
+      X01[i] = P2{ux ? xu[i] : T(0), vx ? xv[i] : T(0)}; X2[i] = wx ? xw[i] : T(0);
+      // rhs' rides in the reduction: every lane of a half starts its partial sum at -rhs'/8 (exact scaling), so the reduced
+      // value is J'.acc - rhs' and the row update needs one subtraction instead of an add and a subtract
+      rh[i] = r_own >= 0 ? rhs_[i] * T(-0.125) : T(0);
+      if constexpr (EXIT) th[i] = r_own >= 0 ? th[i] : T(0);
+      // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
+      // partner's B~; half 0 takes 0 (its row does not wait for anybody)
+      const T c = team_red8(J0[i] * X01[i].x + J1[i] * X01[i].y + J2[i] * X2[i]);
+      cp[i] = half ? c : T(0);
+      // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
+      const T lx_ = half_swap(lm[i]);
+      if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx_;
+      a01 = fm(X01[i], P2{lx_, lx_}, fm(B01[i], P2{lm[i], lm[i]}, a01)); a2 = fm(X2[i], lx_, fm(B2[i], lm[i], a2));
+    });
   });
   // couplings with the predecessor slot (wrapping around: the first slot follows the last one of the previous sweep)
   static_for<n>([&](auto ic) {
@@ -1684,32 +1754,45 @@ SNI_SCALAR void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev,
   if (!valid) return;
   SubCtx<T, ROBOT>& C = ch.get();
   const T dt = pp.dt;
+  // LOAD everything this lane needs (two LDS round trips: the context, then the impulses whose positions depend on the contact mask)
+  // -> compute -> STORE: a read behind a store is a round trip of its own (LDS pointers may alias as far as the compiler knows), and this
+  // phase used to make thirteen of them
   const int mask = C.mask;
-  const T* lam = TRW::lam(lds.lane);
-  const int npos0 = TRW::NPOS0 + extra_limits(C.nlim_total);
-  for (int p = t; p < NPRIM; p += 16) {       // warm-start cache: normal impulse of primitive p (its rank among the contacts)
-    const T l = ((mask >> p) & 1) ? lam[(npos0 + __builtin_popcount(mask & ((1 << p) - 1))) * 4] : T(0);
-    C.lamp[p] = l;
-  }
+  const int nlt = C.nlim_total;
   const T* hdr = lds.hdr();
   const SV<T> w{{hdr[2 * LN], hdr[3 * LN], hdr[4 * LN]}, {hdr[5 * LN], hdr[6 * LN], hdr[7 * LN]}};
-  if (t < RB::NQ) {
-    const int L = t / NJ, k = t - L * NJ;
-    const T nv = clampv(C.qds[t] + lds.y()[(L * 3 + k) * LN] - dot(C.LR[L].G[k], w), pp.vmax);
-    C.ps.qd[t] = nv;
-    C.ps.q[t] += dt * nv;
+  const int tj = t < RB::NQ ? t : 0;                 // (every lane reads a valid joint's operands; lanes >= NQ discard them)
+  const int L = tj / NJ, k = tj - L * NJ;
+  const T qds = C.qds[tj], yk = lds.y()[(L * 3 + k) * LN], qj = C.ps.q[tj];
+  const SV<T> Gk = C.LR[L].G[k];
+  const SV<T> ub = C.ub;
+  const V3<T> pos = C.ps.pos;
+  const T x = C.ps.qx, yq = C.ps.qy, z = C.ps.qz, ww = C.ps.qw;
+  const T* lam = TRW::lam(lds.lane);
+  const int npos0 = TRW::NPOS0 + extra_limits(nlt);
+  T lv[(NPRIM + 15) / 16];
+#pragma unroll
+  for (int i = 0; i < (NPRIM + 15) / 16; i++) {      // warm-start cache: normal impulse of primitive p (its rank among the contacts)
+    const int p = t + 16 * i;
+    const int pp_ = p < NPRIM ? p : 0;
+    lv[i] = lam[(npos0 + __builtin_popcount(mask & ((1 << pp_) - 1))) * 4];
+    lv[i] = (p < NPRIM && ((mask >> pp_) & 1)) ? lv[i] : T(0);
   }
+  // ---- compute
+  const T nvj = clampv(qds + yk - dot(Gk, w), pp.vmax);
+  const V3<T> nw = mk(clampv(ub.a.x + w.a.x, pp.vmax), clampv(ub.a.y + w.a.y, pp.vmax), clampv(ub.a.z + w.a.z, pp.vmax));
+  const V3<T> nv = mk(clampv(ub.l.x + w.l.x, pp.vmax), clampv(ub.l.y + w.l.y, pp.vmax), clampv(ub.l.z + w.l.z, pp.vmax));
+  // ---- store
+#pragma unroll
+  for (int i = 0; i < (NPRIM + 15) / 16; i++) { const int p = t + 16 * i; if (p < NPRIM) C.lamp[p] = lv[i]; }
+  if (t < RB::NQ) { C.ps.qd[t] = nvj; C.ps.q[t] = qj + dt * nvj; }
   if (lead) {
-    const SV<T> ub = C.ub;
-    const V3<T> nw = mk(clampv(ub.a.x + w.a.x, pp.vmax), clampv(ub.a.y + w.a.y, pp.vmax), clampv(ub.a.z + w.a.z, pp.vmax));
-    const V3<T> nv = mk(clampv(ub.l.x + w.l.x, pp.vmax), clampv(ub.l.y + w.l.y, pp.vmax), clampv(ub.l.z + w.l.z, pp.vmax));
     C.ps.w = nw; C.ps.v = nv;
-    C.ps.pos = fma3(nv, dt, C.ps.pos);
+    C.ps.pos = fma3(nv, dt, pos);
     T wn2 = dot(nw, nw), wn = sqrt(wn2), sc, s_, cw;
     sincos_t(T(0.5) * wn * dt, s_, cw);
     if (wn < T(1e-3)) sc = T(0.5) * dt - dt * dt * dt * T(1.0 / 48.0) * wn2; else sc = s_ / wn;
     T ax = nw.x * sc, ay = nw.y * sc, az = nw.z * sc;
-    T x = C.ps.qx, yq = C.ps.qy, z = C.ps.qz, ww = C.ps.qw;
     T nx = cw * x + ax * ww + ay * z - az * yq;
     T ny = cw * yq - ax * z + ay * ww + az * x;
     T nz = cw * z + ax * yq - ay * x + az * ww;

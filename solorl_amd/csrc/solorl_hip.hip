@@ -991,8 +991,23 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   return p;
 }
 
+// The phase functions address the dynamic LDS from the constant SOLO_LDS_BASE (dynamics.hpp): true exactly while a step kernel's
+// static LDS has that size.  Checked against the loaded code object, once per kernel and process.
+static int check_lds_base(const void* kernel, bool& checked) {
+  if (checked) return 0;
+  hipFuncAttributes a;
+  HIP_TRY(hipFuncGetAttributes(&a, kernel));
+  if (a.sharedSizeBytes != (size_t)SOLO_LDS_BASE)
+    return fail(SOLORL_ERR_HIP, "step kernel has static LDS: the phase functions' dynamic-LDS base constant does not hold");
+  checked = true;
+  return 0;
+}
+
 template <typename T, int ROBOT>
 int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
+  static bool lds_checked[2] = {false, false};
+  if (int rc = check_lds_base(h->team ? reinterpret_cast<const void*>(step_kernel_team<T, ROBOT>) : reinterpret_cast<const void*>(step_kernel<T, ROBOT>),
+                              lds_checked[h->team ? 1 : 0])) return rc;
   if (h->team) {
     auto kt = step_kernel_team<T, ROBOT>;
     dim3 grid((((N + 3) / 4) + 7) & ~7), block(64);      // multiple of 8: XCD-contiguous env ranges (step_body)

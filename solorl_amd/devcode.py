@@ -19,6 +19,26 @@ def disassemble(lib_path):
         return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
 
 
+def kernel_static_lds(lib_path):
+    """{kernel name: static LDS bytes (.group_segment_fixed_size of the code object's metadata)}"""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path, os.path.join(d, "x.so")])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    out, size = {}, None
+    for line in notes.splitlines():       # per kernel the keys come in alphabetical order: the size line precedes the name line
+        m = re.search(r"\.group_segment_fixed_size:\s*(\d+)", line)
+        if m:
+            size = int(m.group(1))
+        m = re.search(r"^\s*\.name:\s*(\S+)", line)
+        if m and size is not None:
+            out[m.group(1)] = size
+            size = None
+    return out
+
+
 def function_stats(lib_path):
     """{mangled name: {"insts", "scratch", "flat", "global"}}"""
     out, cur = {}, None

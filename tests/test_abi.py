@@ -107,6 +107,16 @@ def test_reference_yaml_configs_load():
         config_from_dict(dict(episode_length=10, task="fly"))
 
 
+def test_step_kernels_have_no_static_lds(lib):
+    """The phase functions address the dynamic LDS from a constant base (dynamics.hpp, SOLO_LDS_BASE = 0): only true while no step
+    kernel has static LDS (the compiler once promoted a private array of the fp64 team kernel into 3 KB of it).  solorl_step checks
+    the same against the loaded code object (hipFuncGetAttributes)."""
+    from solorl_amd import devcode
+    sizes = {k: v for k, v in devcode.kernel_static_lds(build.LIB).items() if "step_kernel" in k}
+    assert len(sizes) == 8, sorted(sizes)       # {lane, team} x {fp32, fp64} x {Solo8, Solo12}
+    assert all(v == 0 for v in sizes.values()), sizes
+
+
 def test_team_mode_phases_do_not_spill_or_use_flat(lib):
     """Static check of the built code object: the fp32 Solo12/Solo8 team-mode phases keep their state in VGPRs
     and LDS (no scratch traffic, no FLAT access to the context); the sweeps of up to 6 contacts -- 99.6 % of the
