@@ -1509,6 +1509,12 @@ template <typename T> SD T team_red8(T x) {      // sum over the 8 lanes of a ha
 //   slot, a 6-operation shorter dependency chain).  Measured: faster when a wavefront has its SIMD to itself (<= 4096 envs:
 //   0.172 vs 0.180 ms per step), slower when two wavefronts share one and issue slots are what counts (8192 envs: 0.229 vs
 //   0.223 ms) -- the launcher picks by grid size (PhysParams::pgs_pipe).  The K7 variants are always pipelined.
+#ifndef SOLO_SETUP_GROUP_F32
+#define SOLO_SETUP_GROUP_F32 5
+#endif
+#ifndef SOLO_SETUP_GROUP_F64
+#define SOLO_SETUP_GROUP_F64 1
+#endif
 template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT, bool PIPE = true>
 SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // (the residual threshold of K7 reaches the sweep through the rows: phase_finish_team stores it per row, in the row's units)
@@ -1560,7 +1566,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // In groups of SETUP_GROUP slots (all 13 at once would need ~210 registers for the raw values alone): reads of the group, a compiler
   // barrier for memory operations, a second one that re-defines the read values (an empty asm with "+v" operands -- without it the
   // scheduler hoists each slot's arithmetic, which is not a memory operation, back up to its reads and the round trips are per slot again).
-  constexpr int SETUP_GROUP = 5;
+  constexpr int SETUP_GROUP = sizeof(T) == 4 ? SOLO_SETUP_GROUP_F32 : SOLO_SETUP_GROUP_F64;      // (fp64: a value is a register pair -- groups of 5 / 2 / 1 slots: 1.37 / 1.36 / 1.21 ms per step)
   static_for<(n + SETUP_GROUP - 1) / SETUP_GROUP>([&](auto gc) {
     constexpr int g0 = decltype(gc)::value * SETUP_GROUP, gn = (n - g0 < SETUP_GROUP ? n - g0 : SETUP_GROUP);
     static_for<gn>([&](auto jc) {
@@ -1581,8 +1587,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       constexpr int i = g0 + decltype(jc)::value;
       asm volatile("" : "+v"(ju[i]), "+v"(bu[i]), "+v"(jv[i]), "+v"(bv[i]), "+v"(jw[i]), "+v"(bw[i]), "+v"(xu[i]), "+v"(xv[i]), "+v"(xw[i]),
                         "+v"(rhs_[i]), "+v"(lm[i]), "+v"(lego[i]), "+v"(legx[i]));
-      T& thi = th[EXIT ? i : 0];
-      if constexpr (EXIT) asm volatile("" : "+v"(thi));
+      (void)th;                       // (named outside the discarded branch: a generic lambda captures it only then)
+      if constexpr (EXIT) asm volatile("" : "+v"(th[i]));
     });
 #endif
     static_for<gn>([&](auto jc) {
@@ -1640,6 +1646,9 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // any team became quiet in this sweep (round 2 split the wave's ballot into four team masks on the scalar unit: ~25 instructions
   // per sweep, a twelfth of a 6-slot sweep; now ~9).
   bool fin = false;                                                   // this lane's team is finished (uniform within the team)
+#if defined(SOLO_WAVE_TIMING) && defined(SOLO_DEAD_STATS)      // (its own switch: the wave-wide test in every friction slot slows the sweep by a tenth)
+  unsigned long long fr_tot = 0, fr_dead = 0;                         // friction-slot visits / those with zero bound and zero impulse in every lane
+#endif
 #pragma unroll 1                                                    // (unrolled by two: no change, measured)
   for (int it = 0; it < iterations; it++) {
     bool viol = false;
@@ -1662,6 +1671,9 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
         else if constexpr (sizeof(T) == 4) return __builtin_amdgcn_fmed3f(x, -hi, hi);
         else return x < -hi ? -hi : (x > hi ? hi : x);
       };
+#if defined(SOLO_WAVE_TIMING) && defined(SOLO_DEAD_STATS)
+      if constexpr (fric) { fr_tot++; if (!__any(hi != T(0) || lm[i] != T(0))) fr_dead++; }
+#endif
       T sp = lm[i] - d;
       // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
       // (cp = 0 in half 0, whose second clamp therefore repeats the first)
@@ -1689,6 +1701,9 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   }
   if constexpr (EXIT) { if (!fin) SOLO_PGS_WRITE_BACK(); }     // teams that ran all the iterations
   else SOLO_PGS_WRITE_BACK();
+#if defined(SOLO_WAVE_TIMING) && defined(SOLO_DEAD_STATS)
+  if (threadIdx.x == 0 && blockIdx.x < SOLO_WT_WAVES) { solo_wave_times[blockIdx.x][26] += fr_tot; solo_wave_times[blockIdx.x][27] += fr_dead; }
+#endif
 #undef SOLO_PGS_WRITE_BACK
 }
 

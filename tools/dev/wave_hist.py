@@ -54,6 +54,9 @@ print("intervals between stamps (us; mean over all wavefronts | over the slowest
 slow_ = tot >= np.percentile(tot, 99)
 for i, n_ in enumerate(segs):
     print("  %-28s %7.2f | %7.2f" % (n_, us(R[:, :, 6 + i].mean()), us(R[:, :, 6 + i][slow_].mean())))
+fr = R[:, :, 26].sum(); frs = R[:, :, 26][slow_].sum()
+if fr > 0: print("friction-slot visits with zero bound and zero impulse in every lane of the wavefront (a skip would be value-exact): %.1f %% of all, %.1f %% in the slowest 1 %% of the wavefronts" % (
+    100.0 * R[:, :, 27].sum() / max(fr, 1), 100.0 * R[:, :, 27][slow_].sum() / max(frs, 1)))
 phases = ["sin/cos", "collision front", "legs (4 lanes)", "leg sum", "base solve (leader)", "leg rates", "row finish", "PGS sweep", "integrate"]
 print("phases of the sub-steps, summed over a step's %d sub-steps (us; mean over all wavefronts | over the slowest 1 %%; timing build drains the memory counters at every stamp):" % c.frame_skip)
 for i, n_ in enumerate(phases):
