@@ -1519,7 +1519,9 @@ template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT, bool P
 SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // (the residual threshold of K7 reaches the sweep through the rows: phase_finish_team stores it per row, in the row's units)
   using TRW = TeamRows<T, LDS>;
-  const int iterations = __builtin_amdgcn_readfirstlane(iterations_v);   // function arguments arrive in VGPRs: make the sweep loop scalar
+  const int itv = __builtin_amdgcn_readfirstlane(iterations_v);          // function arguments arrive in VGPRs: make the sweep loop scalar
+  const int iterations = itv & 0xFFFF;
+  const bool warm_on = (itv >> 30) & 1;                                  // (bit 30: the rows carry warm-start impulses, phase_pgs_team)
   constexpr int LN = LDS::LANES, n = LIM + NNS + NFS;
   constexpr int S_N0 = 1, S_F0 = 1 + MAX_CONTACTS / 2;      // slot numbers of the first normal / friction slot
   static_assert(n >= 1, "empty sweeps are not instantiated");
@@ -1541,9 +1543,13 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   const int eW = E_JL + 1 + h, legW = h < 2 ? 3 : -2; // -2: no row (the zero pair)
   constexpr int dJB = E_BB - E_JB;                    // J' element -> B~ element (base: +9, leg: +9 as well)
   static_assert(E_BL - E_JL == dJB, "record layout");
-  auto elem = [&](int r, int e) -> T {                // element e of parked row r
-    return *reinterpret_cast<const T*>(solo_smem + ((unsigned)((r * LDS::NCH + e / LDS::PER) * LN + col) * 16u + (unsigned)(e % LDS::PER) * SZ));
-  };
+  // element e of parked row r sits at r * ROWB + eoff(e): the lane's six element offsets are computed once, a read is one add away from its
+  // row base (written as one expression per read the compiler rebuilt the whole index arithmetic each time: 35 instructions per slot for 13 reads)
+  constexpr unsigned ROWB = (unsigned)LDS::NCH * LN * 16u;
+  auto eoff = [&](int e) -> unsigned { return (unsigned)(e / LDS::PER) * (LN * 16u) + (unsigned)(e % LDS::PER) * SZ + (unsigned)col * 16u; };
+  const unsigned kU = eoff(eU), kUB = eoff(eU + dJB), kV = eoff(eV), kVB = eoff(eV + dJB), kW = eoff(eW), kWB = eoff(eW + dJB);
+  const unsigned kLEG = eoff(E_LEG), kRHS = eoff(E_RHS);
+  auto rd = [&](unsigned rb, unsigned k) -> T { return *reinterpret_cast<const T*>(solo_smem + (rb + k)); };
   // all arrays below are indexed by the sweep index i.  The B~ / X~ columns of accumulator components 0 and 1 are kept as
   // explicit 2-vectors (v_pk_fma_f32 on fp32; the translation unit is built with -fno-slp-vectorize, so what is packed
   // is exactly what is written here -- left to itself the vectoriser paired unrelated multiplies of the slot's dependency
@@ -1572,12 +1578,17 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     static_for<gn>([&](auto jc) {
       constexpr int i = g0 + decltype(jc)::value;
       constexpr int k = Ord::slot(i);
-      rown[i] = TRW::row_of(2 * k + half, nlt, nc); roth[i] = TRW::row_of(2 * k + 1 - half, nlt, nc);
+      constexpr bool fr = i >= LIM + NNS;     // friction slot: its two rows are the two directions of ONE contact -- consecutive rows, present together, same leg
+      rown[i] = TRW::row_of(2 * k + half, nlt, nc);
+      if constexpr (fr) roth[i] = rown[i] < 0 ? -1 : rown[i] + 1 - 2 * half;
+      else roth[i] = TRW::row_of(2 * k + 1 - half, nlt, nc);
       const int ro = rown[i] < 0 ? 0 : rown[i], rx = roth[i] < 0 ? 0 : roth[i];        // (a safe row to read; the value is discarded)
-      lego[i] = elem(ro, E_LEG); legx[i] = elem(rx, E_LEG);
-      ju[i] = elem(ro, eU); bu[i] = elem(ro, eU + dJB); jv[i] = elem(ro, eV); bv[i] = elem(ro, eV + dJB); jw[i] = elem(ro, eW); bw[i] = elem(ro, eW + dJB);
-      xu[i] = elem(rx, eU + dJB); xv[i] = elem(rx, eV + dJB); xw[i] = elem(rx, eW + dJB);
-      rhs_[i] = elem(ro, E_RHS);
+      const unsigned bo = __umul24((unsigned)ro, ROWB), bx = __umul24((unsigned)rx, ROWB);   // record address = row base + the lane's element offset (24-bit multiply: full rate)
+      lego[i] = rd(bo, kLEG);
+      if constexpr (!fr) legx[i] = rd(bx, kLEG); else legx[i] = T(0);
+      ju[i] = rd(bo, kU); bu[i] = rd(bo, kUB); jv[i] = rd(bo, kV); bv[i] = rd(bo, kVB); jw[i] = rd(bo, kW); bw[i] = rd(bo, kWB);
+      xu[i] = rd(bx, kUB); xv[i] = rd(bx, kVB); xw[i] = rd(bx, kWB);
+      rhs_[i] = rd(bo, kRHS);
       if constexpr (EXIT) th[i] = lds.A(ro, LDS::A_LAM);
       lm[i] = *reinterpret_cast<const T*>(solo_smem + lam_own + 2 * k * S_LAM);
     });
@@ -1586,33 +1597,44 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
     static_for<gn>([&](auto jc) {
       constexpr int i = g0 + decltype(jc)::value;
       asm volatile("" : "+v"(ju[i]), "+v"(bu[i]), "+v"(jv[i]), "+v"(bv[i]), "+v"(jw[i]), "+v"(bw[i]), "+v"(xu[i]), "+v"(xv[i]), "+v"(xw[i]),
-                        "+v"(rhs_[i]), "+v"(lm[i]), "+v"(lego[i]), "+v"(legx[i]));
+                        "+v"(rhs_[i]), "+v"(lm[i]), "+v"(lego[i]));
+      (void)legx;
+      if constexpr (i < LIM + NNS) asm volatile("" : "+v"(legx[i]));
       (void)th;                       // (named outside the discarded branch: a generic lambda captures it only then)
       if constexpr (EXIT) asm volatile("" : "+v"(th[i]));
     });
 #endif
     static_for<gn>([&](auto jc) {
       constexpr int i = g0 + decltype(jc)::value;
+      constexpr bool fr = i >= LIM + NNS;
       const int r_own = rown[i], r_oth = roth[i];
-      const int lo = r_own < 0 ? -3 : (int)lego[i], lx = r_oth < 0 ? -3 : (int)legx[i];
+      const int lo = r_own < 0 ? -3 : (int)lego[i], lx = fr ? lo : (r_oth < 0 ? -3 : (int)legx[i]);
       const bool uo = r_own >= 0 && (legU == -1 || legU == lo), vo = legV == lo, wo = legW == lo;
-      const bool ux = r_oth >= 0 && (legU == -1 || legU == lx), vx = legV == lx, wx = legW == lx;
+      const bool ux = fr ? uo : (r_oth >= 0 && (legU == -1 || legU == lx)), vx = fr ? vo : legV == lx, wx = fr ? wo : legW == lx;
       J0[i] = uo ? ju[i] : T(0); J1[i] = vo ? jv[i] : T(0); J2[i] = wo ? jw[i] : T(0);
       B01[i] = P2{uo ? bu[i] : T(0), vo ? bv[i] : T(0)}; B2[i] = wo ? bw[i] : T(0);
       X01[i] = P2{ux ? xu[i] : T(0), vx ? xv[i] : T(0)}; X2[i] = wx ? xw[i] : T(0);
       // rhs' rides in the reduction: every lane of a half starts its partial sum at -rhs'/8 (exact scaling), so the reduced
       // value is J'.acc - rhs' and the row update needs one subtraction instead of an add and a subtract
       rh[i] = r_own >= 0 ? rhs_[i] * T(-0.125) : T(0);
-      if constexpr (EXIT) th[i] = r_own >= 0 ? th[i] : T(0);
+      // (th of a null row: that of the safe row 0, >= 0 -- a finished row's, or 0 as parked by phase_base_lead for a team without rows -- and a
+      // null row's delta is 0, never above it)
       // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
       // partner's B~; half 0 takes 0 (its row does not wait for anybody)
       const T c = team_red8(J0[i] * X01[i].x + J1[i] * X01[i].y + J2[i] * X2[i]);
       cp[i] = half ? c : T(0);
-      // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0)
-      const T lx_ = half_swap(lm[i]);
-      if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx_;
-      a01 = fm(X01[i], P2{lx_, lx_}, fm(B01[i], P2{lm[i], lm[i]}, a01)); a2 = fm(X2[i], lx_, fm(B2[i], lm[i], a2));
+      if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = T(0);
     });
+    // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0).  With PyBullet's default (no multibody warm start, the engine's
+    // too) every lam0 read above is zero and the whole accumulation is skipped: one uniform branch per group.
+    if (warm_on) {
+      static_for<gn>([&](auto jc) {
+        constexpr int i = g0 + decltype(jc)::value;
+        const T lx_ = half_swap(lm[i]);
+        if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = lx_;
+        a01 = fm(X01[i], P2{lx_, lx_}, fm(B01[i], P2{lm[i], lm[i]}, a01)); a2 = fm(X2[i], lx_, fm(B2[i], lm[i], a2));
+      });
+    }
   });
   // couplings with the predecessor slot (wrapping around: the first slot follows the last one of the previous sweep)
   static_for<n>([&](auto ic) {
@@ -1708,7 +1730,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
 }
 
 template <typename T, int ROBOT, typename LDS>
-SD void phase_pgs_team(int iterations, bool early_exit, bool pipe, const LDS lds, int t) {
+SD void phase_pgs_team(int iterations_, bool warm_on, bool early_exit, bool pipe, const LDS lds, int t) {
+  const int iterations = (iterations_ & 0xFFFF) | (warm_on ? 1 << 30 : 0);       // (one argument register: pgs_team_variant)
   constexpr int LN = LDS::LANES;
   int nlt, nc, ncmax, anylim;
   team_counts<T, LDS>(lds, nlt, nc, ncmax, anylim);
@@ -1870,7 +1893,7 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #endif
   SOLO_PT(6);
-  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.resid_thr >= T(0), pp.pgs_pipe != 0, lds, t);
+  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.warm != T(0), pp.resid_thr >= T(0), pp.pgs_pipe != 0, lds, t);
   SOLO_PT(7);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
   SOLO_PT(8);

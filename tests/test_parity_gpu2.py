@@ -369,13 +369,16 @@ def test_episode_stat_accumulators(gpu_device):
 
 
 # ------------------------------------------------------------------------------------------------ K7 early exit (opt-in)
-def test_plain_sweep_variant_vs_oracle(gpu_device):
-    """Above one wavefront per SIMD (more than 4096 envs on an MI355X) the team-mode sweep runs without the software
-    pipelining (3 instructions fewer per slot).  Forced here at a size the oracle can follow (SOLORL_PGS_PIPE=0): same
-    per-step bounds as the default variant, and the two variants agree with each other to rounding."""
+@pytest.mark.parametrize("warmstart", [0.0, 0.85])
+def test_fixed_sweep_variants_vs_oracle(gpu_device, warmstart):
+    """solver_residual_threshold = 0 (fixed 50 sweeps, round 2's default): above one wavefront per SIMD (more than 4096 envs on an
+    MI355X) the team-mode sweep then runs without the software pipelining (3 instructions fewer per slot).  Both variants forced here at a
+    size the oracle can follow (SOLORL_PGS_PIPE=0 / 1): same per-step bounds as the default (residual-exit) variant, and the two agree with
+    each other to rounding.  With and without the multibody warm start (the sweep's set-up skips the warm-start accumulation when the
+    config has none: both paths are exercised)."""
     from solorl_amd.vec_env import SoloVecEnv
     from oracle.oracle_py import Oracle
-    c = cfg_for(ROBOT_SOLO12, TASK_WALK)
+    c = cfg_for(ROBOT_SOLO12, TASK_WALK, solver_residual_threshold=0.0, warmstart=warmstart)
     N = 128
     envs = {}
     for pipe in (0, 1):
@@ -385,6 +388,7 @@ def test_plain_sweep_variant_vs_oracle(gpu_device):
         finally:
             del os.environ["SOLORL_PGS_PIPE"]
         envs[pipe].reset()
+        assert envs[pipe].get_property("sweep_variant") == pipe        # 0 plain, 1 pipelined, 2 residual exit
     orc = Oracle(c, N, seed=3, threads=8); orc.reset()
     rng = np.random.default_rng(0)
     dq, dv = [], []
