@@ -690,7 +690,9 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
   constexpr int ST = NJ + 1;   // links per leg
-  const T kd = pp.damping;
+  // every field of pp this phase uses, read HERE: pp arrives by reference (a FLAT load from the kernel's stack, ~700 cycles), and read where it is
+  // used -- inside the blocks of the contact rows -- each touching primitive waited for its own round trip
+  const T kd = pp.damping, pp_qlim = pp.qlim, pp_slop = pp.slop, pp_warm = pp.warm, pp_tm_mu = pp.tm_mu;
   const M3<T> R0 = C.R0;
   SV<T> vp{C.ps.w, C.ps.v};
   T sn[NJ], cs[NJ], qd[NJ], q[NJ], tau[NJ];
@@ -802,7 +804,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       for (int side = 0; side < 2; side++) {
         const int bit = 2 * (L * NJ + k) + side;
         if ((lsel >> bit) & 1) {
-          T pen = side == 0 ? q[k] + pp.qlim : pp.qlim - q[k];
+          T pen = side == 0 ? q[k] + pp_qlim : pp_qlim - q[k];
           T sg = side == 0 ? T(1) : T(-1);
           T JL[3] = {T(0), T(0), T(0)}, Y[3] = {Minv[0][k] * sg, Minv[1][k] * sg, Minv[2][k] * sg};
           JL[k] = sg;
@@ -822,10 +824,10 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       const int cidx = __builtin_popcount(mask & ((1 << p) - 1));
       const int slot_n = nlt + cidx, slot_f = nlt + nc + 2 * cidx;
       const V3<T> P = i == 0 ? C.kneeP[L] : (i == 1 ? C.footP[L] : C.shP[L]);
-      const T pen = C.dist[p] + pp.slop;
-      const T lam0 = pp.warm * C.lamp[p];
+      const T pen = C.dist[p] + pp_slop;
+      const T lam0 = pp_warm * C.lamp[p];
       const T fric = SEL4(T, lsg, RB::MD.prims[P0].friction, RB::MD.prims[P0 + PS].friction, RB::MD.prims[P0 + 2 * PS].friction,
-                          RB::MD.prims[P0 + 3 * PS].friction) * (((C.smask >> p) & 1) ? pp.tm_mu : T(1));
+                          RB::MD.prims[P0 + 3 * PS].friction) * (((C.smask >> p) & 1) ? pp_tm_mu : T(1));
       static_for<3>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
