@@ -224,8 +224,8 @@ SD void link_terms(const M3<T>& R, V3<T> cw, T m, T ix, T iy, T iz, SV<T> v, T k
   if constexpr (OD & 4) add_od(iyz, R.c1, R.c2);
   V3<T> vc = v.l + cross(v.a, cw);
   V3<T> Icw = mul(Ic, v.a);
-  T kl = kd + kd * sqrt(dot(vc, vc));
-  T ka = kd + kd * sqrt(dot(v.a, v.a));
+  T kl = kd + kd * sqrt_fast(dot(vc, vc));
+  T ka = kd + kd * sqrt_fast(dot(v.a, v.a));
   V3<T> fc = (cross(v.a, vc) + vc * kl) * m;
   V3<T> nc = cross(v.a, Icw) + Icw * ka;
   p.a = nc + cross(cw, fc);
@@ -250,7 +250,7 @@ template <typename T> SD V3<T> addc(V3<T> o, const M3<T>& R, double x, double y,
 // of asin(DISC_RIM), so a link lying on its side rests half a thickness lower, as its hull does; oracle: prim_point)
 template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius, T halfw = T(0)) {
   T dx = -R.c0.z, dz = -R.c2.z;                       // world-down expressed in the link's x,z
-  T s = radius / sqrt(dx * dx + dz * dz + T(DISC_EPS2));
+  T s = radius * rsqrt_fast(dx * dx + dz * dz + T(DISC_EPS2));
   V3<T> P = C + R.c0 * (dx * s) + R.c2 * (dz * s);
   T w = -R.c1.z * T(1.0 / DISC_RIM);                  // world-down along the axis, in rim units
   w = w > T(1) ? T(1) : (w < T(-1) ? T(-1) : w);
@@ -259,7 +259,7 @@ template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius, T h
 // the same for a disc about the link's x axis (shoulder housings)
 template <typename T> SD V3<T> disc_point_x(const M3<T>& R, V3<T> C, T radius) {
   T dy = -R.c1.z, dz = -R.c2.z;                       // world-down expressed in the link's y,z
-  T s = radius / sqrt(dy * dy + dz * dz + T(DISC_EPS2));
+  T s = radius * rsqrt_fast(dy * dy + dz * dz + T(DISC_EPS2));
   return C + R.c1 * (dy * s) + R.c2 * (dz * s);
 }
 
@@ -749,7 +749,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       constexpr int k = NJ - 1 - decltype(kc)::value;
       SV<T> S = Sk[k];
       SV<T> U = mul(IA, S);
-      T Dinv = T(1) / dot(S, U);
+      T Dinv = rcp_fast(dot(S, U));
       T u = tau[k] - dot(S, pA);
       Uk[k] = U; Dk[k] = Dinv; uk[k] = u;
       rank1_sub(IA, U, Dinv);
@@ -921,7 +921,7 @@ SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const S
   const T rel = dot(cross(P, u), ub.a) + dot(u, ub.l) + c[6] * q0 + c[7] * q1 + c[8] * q2;
   W = mul(Lam, f0);
   const T denom = dot(f0, W) + c[6] * c[15] + c[7] * c[16] + c[8] * c[17];
-  dinv = T(1) / denom;
+  dinv = rcp_fast(denom);
   if (meta & 128) rhs = -rel * dinv;
   else {
     const T pen = c[12];
@@ -1455,13 +1455,14 @@ SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) 
     finish_row(c, meta, Lam, ub, ql[0], ql[1], ql[2], pp, W, rhs, dinv);
     const bool fr = r >= rfric;
     const T sB = fr ? mu : T(1);
-    const T sJ = dinv / sB;
+    const T isB = rcp_fast(sB);
+    const T sJ = dinv * isB;
     T o[ROW_CORE];
     o[E_JB + 0] = c[0] * sJ; o[E_JB + 1] = c[1] * sJ; o[E_JB + 2] = c[2] * sJ; o[E_JB + 3] = c[3] * sJ; o[E_JB + 4] = c[4] * sJ; o[E_JB + 5] = c[5] * sJ;
     o[E_JL + 0] = c[6] * sJ; o[E_JL + 1] = c[7] * sJ; o[E_JL + 2] = c[8] * sJ;
     o[E_BB + 0] = W.a.x * sB; o[E_BB + 1] = W.a.y * sB; o[E_BB + 2] = W.a.z * sB; o[E_BB + 3] = W.l.x * sB; o[E_BB + 4] = W.l.y * sB; o[E_BB + 5] = W.l.z * sB;
     o[E_BL + 0] = c[15] * sB; o[E_BL + 1] = c[16] * sB; o[E_BL + 2] = c[17] * sB;
-    o[E_RHS] = rhs / sB;                // finish_row's rhs already carries 1/diag
+    o[E_RHS] = rhs * isB;               // finish_row's rhs already carries 1/diag
     o[E_LEG] = T(leg);
     lds.store_core(r, o);
     lds.A(r, LDS::A_LAM) = pp.resid_thr * sJ;      // K7 in the row's units: |delta lambda~| / sJ = |delta impulse| / jacDiagABInv
@@ -1829,15 +1830,15 @@ SNI_SCALAR void phase_integrate_team(CH ch, const PhysParams<T> pp, T* lam_prev,
   if (lead) {
     C.ps.w = nw; C.ps.v = nv;
     C.ps.pos = fma3(nv, dt, pos);
-    T wn2 = dot(nw, nw), wn = sqrt(wn2), sc, s_, cw;
+    T wn2 = dot(nw, nw), wn = sqrt_fast(wn2), sc, s_, cw;
     sincos_t(T(0.5) * wn * dt, s_, cw);
-    if (wn < T(1e-3)) sc = T(0.5) * dt - dt * dt * dt * T(1.0 / 48.0) * wn2; else sc = s_ / wn;
+    if (wn < T(1e-3)) sc = T(0.5) * dt - dt * dt * dt * T(1.0 / 48.0) * wn2; else sc = s_ * rcp_fast(wn);
     T ax = nw.x * sc, ay = nw.y * sc, az = nw.z * sc;
     T nx = cw * x + ax * ww + ay * z - az * yq;
     T ny = cw * yq - ax * z + ay * ww + az * x;
     T nz = cw * z + ax * yq - ay * x + az * ww;
     T nq = cw * ww - ax * x - ay * yq - az * z;
-    T inv = T(1) / sqrt(nx * nx + ny * ny + nz * nz + nq * nq);
+    T inv = rsqrt_fast(nx * nx + ny * ny + nz * nz + nq * nq);
     C.ps.qx = nx * inv; C.ps.qy = ny * inv; C.ps.qz = nz * inv; C.ps.qw = nq * inv;
   }
 }

@@ -24,6 +24,32 @@
 
 namespace solo {
 
+// Reciprocal / square root of the hot phases.  fp32 on the GPU: the hardware approximations (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp),
+// the reciprocal with one Newton step -- an IEEE-rounded fp32 division is a 10-instruction sequence (v_div_scale x2, v_rcp, 4 FMAs,
+// v_div_fmas, v_div_fixup), a rounded square root 8, and the serial phases run ~20 of them per sub-step.  fp64 (the validation
+// precision) and the host build keep the exact operations.
+template <typename T> SD T rcp_fast(T x) {
+#ifndef SOLO_HOST_SHIM
+  if constexpr (sizeof(T) == 4) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); }
+  else
+#endif
+  return T(1) / x;
+}
+template <typename T> SD T sqrt_fast(T x) {
+#ifndef SOLO_HOST_SHIM
+  if constexpr (sizeof(T) == 4) return __builtin_amdgcn_sqrtf(x);
+  else
+#endif
+  return sqrt(x);
+}
+template <typename T> SD T rsqrt_fast(T x) {
+#ifndef SOLO_HOST_SHIM
+  if constexpr (sizeof(T) == 4) { const float r = __builtin_amdgcn_rsqf(x); return r * __builtin_fmaf(__builtin_fmaf(-x * r, r, 1.0f), 0.5f, 1.0f); }
+  else
+#endif
+  return T(1) / sqrt(x);
+}
+
 template <typename T> struct V3 { T x, y, z; };
 
 template <typename T> SD V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
@@ -193,7 +219,7 @@ template <typename T> SD Sym6<T> spd_inverse(const ABI<T>& I) {
 template <typename T> SD Sym3<T> inverse(const Sym3<T>& S) {
   const T c00 = S.yy * S.zz - S.yz * S.yz, c01 = S.xz * S.yz - S.xy * S.zz, c02 = S.xy * S.yz - S.xz * S.yy;
   const T c11 = S.xx * S.zz - S.xz * S.xz, c12 = S.xy * S.xz - S.xx * S.yz, c22 = S.xx * S.yy - S.xy * S.xy;
-  const T r = T(1) / (S.xx * c00 + S.xy * c01 + S.xz * c02);
+  const T r = rcp_fast(S.xx * c00 + S.xy * c01 + S.xz * c02);
   return {c00 * r, c01 * r, c02 * r, c11 * r, c12 * r, c22 * r};
 }
 
