@@ -426,6 +426,44 @@ template <typename T, int ROBOT> SD void scalars_to_lds(const Env<T, Robot<ROBOT
   C.irec[IR_TIMESTEP] = E.timestep; C.irec[IR_MASK] = E.mask; C.irec[IR_RNG] = E.rng;
 }
 
+// current_state (above) spread over the team: lane t produces elements t, t + 16, t + 32 straight from the LDS context -- one read and
+// one multiply each; the three euler angles on lanes 1..3, every one of them running the leader's euler_zyx (same instructions, same
+// bits) and keeping its own angle.  Replaces: the leader copying the whole context to registers (54 reads), computing the D values,
+// staging them through LDS (D stores, a team sync, a read per lane).  Element map: current_state.
+template <typename T, int ROBOT, int HK_>
+SD void team_current_state(const SubCtx<T, ROBOT>& C, int task, int D, int t, T (&cs)[HK_]) {
+  constexpr int NQ = Robot<ROBOT>::NQ;
+  using PS_ = PhysState<T, NQ>;
+  static_assert(offsetof(PS_, v) == 7 * sizeof(T) && offsetof(PS_, q) == 13 * sizeof(T) && sizeof(PS_) == (13 + 2 * NQ) * sizeof(T),
+                "PhysState is a flat array: pos 0-2, quat 3-6, v 7-9, w 10-12, q, qd");
+  const T* psv = reinterpret_cast<const T*>(&C.ps);
+  const int mask = C.irec[IR_MASK];
+  const T g0 = C.erec[ER_GOAL], g1 = C.erec[ER_GOAL + 1];
+  T ang = T(0);
+  if (t >= 1 && t <= 3) {
+    T r, p, y;
+    euler_zyx(C.ps.qx, C.ps.qy, C.ps.qz, C.ps.qw, r, p, y);
+    const T a = t == 1 ? r : (t == 2 ? p : y);
+    ang = (a - T(2) * floor(a * T(0.5))) * T(0.5);   // (euler % 2*pi)/(2*pi) == (euler % 2)/2, solo.py:206
+  }
+#pragma unroll
+  for (int k = 0; k < HK_; k++) {
+    const int d = t + 16 * k;
+    const int e = d - (14 + 2 * NQ);                       // pointgoal extras: pos.x, pos.y, goal x, goal y (all * 0.5)
+    const int idx = d == 0 ? 2 : (d < 10 + 2 * NQ ? d + 3 : (e >= 0 && e < 2 ? e : 0));
+    const T raw = psv[idx];
+    const T sc = d < 10 ? T(1) : (d < 10 + NQ ? T(0.1) : (d < 10 + 2 * NQ ? T(0.01) : T(0.5)));     // (/10, /100: solo.py:208-209)
+    T v = raw * sc;
+    if (d >= 1 && d <= 3) v = ang;
+    const int f = d - (10 + 2 * NQ);
+    if (f >= 0 && f < 4) v = ((mask >> (13 + 2 * f)) & 1) ? T(1) : T(0);     // solo.py:310-323 (see current_state)
+    if (e == 2) v = g0 * T(0.5);
+    if (e == 3) v = g1 * T(0.5);
+    if (task != SOLORL_TASK_POINTGOAL && e >= 0) v = T(0);
+    cs[k] = d < D ? v : T(0);
+  }
+}
+
 // One launch = SoloBaseEnv.step for every env, 16 lanes (one DPP row) per env, 4 envs per wavefront.  Everything on the
 // wavefront's critical path is spread over the team's lanes: the env's state travels HBM <-> LDS with all 16 lanes (4 loads
 // per lane instead of 61 on one), joint t's action, clip and PD torque are lane t's, history / observation / impulse cache /
@@ -473,7 +511,6 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   const CH ch{col};
   SubCtx<T, ROBOT>& C = ch.get();
   T* const psv = reinterpret_cast<T*>(&C.ps);
-  T* const stage = TeamRows<T, LDS>::bc(col);
   idx_t env = 0;
   // ---- the env's state, HBM -> LDS, all lanes (the state is stored by slot: slot e holds env `env`)
   T a_t = T(0);
@@ -506,25 +543,19 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   T hk0[HK], hk1[HK];
 #pragma unroll
   for (int k = 0; k < HK; k++) { hk0[k] = T(0); hk1[k] = T(0); }
+  T csk[HK];
+  if (L.H > 0) team_current_state<T, ROBOT, HK>(C, P.task, L.D, t, csk);
+  TEAM_SYNC();                 // (the leader's stores below: behind every lane's reads of the pre-step context)
   if (lead) {
-    if (L.H > 0) {
-      Env<T, NQ> E;
-      env_from_lds<T, ROBOT>(E, C);
-      T cs[DMAX];
-      current_state<T, ROBOT>(E, P.task, cs);
-#pragma unroll
-      for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
-    }
     C.erec[ER_XYPREV] = C.ps.pos.x; C.erec[ER_XYPREV + 1] = C.ps.pos.y;
     C.tmy = C.erec[ER_TMY];
   }
-  TEAM_SYNC();
   if (valid && L.H > 0) {
 #pragma unroll
     for (int k = 0; k < HK; k++) {
       const int d = t + 16 * k;
       if (d < L.D) {
-        const T c = stage[d];
+        const T c = csk[k];
         if (L.H == 2) { hk1[k] = sf[SX(L.hist + d, e, L.NF)]; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = hk1[k]; }
         sf[SX(L.hist + d, e, L.NF)] = c;
         hk0[k] = c;
@@ -684,15 +715,9 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   WT_STAMP(7);
   // ---- A6 observation (solo.py:186-196): [s, s - hist_newest, s - hist_older], element d on lane d mod 16
   const bool want_obs = mode == MODE_STEP;
-  if (lead && want_obs) {
-    Env<T, NQ> E;
-    env_from_lds<T, ROBOT>(E, C);
-    T cs[DMAX];
-    current_state<T, ROBOT>(E, P.task, cs);
-#pragma unroll
-    for (int d = 0; d < DMAX; d++) stage[d] = cs[d];
-  }
-  TEAM_SYNC();
+  TEAM_SYNC();                 // (a reset's state, written by all lanes above)
+  T cso[HK];
+  if (want_obs) team_current_state<T, ROBOT, HK>(C, P.task, L.D, t, cso);
   WT_STAMP(8);
   if (valid) {
     if (want_obs) {
@@ -701,7 +726,7 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       for (int k = 0; k < HK; k++) {
         const int d = t + 16 * k;
         if (d < L.D) {
-          const T c = stage[d];
+          const T c = cso[k];
           o[d] = (float)c;
           if (L.H >= 1) o[L.D + d] = (float)(c - hk0[k]);
           if (L.H == 2) o[2 * L.D + d] = (float)(c - hk1[k]);
