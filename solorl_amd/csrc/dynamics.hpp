@@ -1674,8 +1674,12 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
 #if defined(SOLO_WAVE_TIMING) && defined(SOLO_DEAD_STATS)      // (its own switch: the wave-wide test in every friction slot slows the sweep by a tenth)
   unsigned long long fr_tot = 0, fr_dead = 0;                         // friction-slot visits / those with zero bound and zero impulse in every lane
 #endif
+  int it_done = 0; (void)it_done;
 #pragma unroll 1                                                    // (unrolled by two: no change, measured)
   for (int it = 0; it < iterations; it++) {
+#if defined(SOLO_WAVE_TIMING) && defined(SOLO_SWEEP_STATS)
+    it_done = it + 1;
+#endif
     bool viol = false;
     static_for<n>([&](auto ic) {
       constexpr int i = decltype(ic)::value, in = (i + 1) % n;
@@ -1726,6 +1730,9 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   }
   if constexpr (EXIT) { if (!fin) SOLO_PGS_WRITE_BACK(); }     // teams that ran all the iterations
   else SOLO_PGS_WRITE_BACK();
+#if defined(SOLO_WAVE_TIMING) && defined(SOLO_SWEEP_STATS)       // sweeps the wavefront ran / solves (instead of the dead-slot counters)
+  if (threadIdx.x == 0 && blockIdx.x < SOLO_WT_WAVES) { solo_wave_times[blockIdx.x][26] += (unsigned long long)it_done; solo_wave_times[blockIdx.x][27] += 1ull; }
+#endif
 #if defined(SOLO_WAVE_TIMING) && defined(SOLO_DEAD_STATS)
   if (threadIdx.x == 0 && blockIdx.x < SOLO_WT_WAVES) { solo_wave_times[blockIdx.x][26] += fr_tot; solo_wave_times[blockIdx.x][27] += fr_dead; }
 #endif

@@ -6,7 +6,7 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if "SOLO_WAVE_TIMING" not in os.environ.get("SOLORL_BUILD_DEFINES", ""):
-    env = dict(os.environ, SOLORL_BUILD_DEFINES=(os.environ.get("SOLORL_BUILD_DEFINES", "") + " SOLO_WAVE_TIMING").strip())
+    env = dict(os.environ, SOLORL_BUILD_DEFINES=(os.environ.get("SOLORL_BUILD_DEFINES", "") + " SOLO_WAVE_TIMING " + os.environ.get("WH_DEFINES", "")).strip())   # WH_DEFINES: SOLO_SWEEP_STATS | SOLO_DEAD_STATS
     subprocess.check_call([sys.executable, "-m", "solorl_amd.build", "-f"], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
     subprocess.check_call([sys.executable, "-m", "solorl_amd.build", "-f"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -55,7 +55,11 @@ slow_ = tot >= np.percentile(tot, 99)
 for i, n_ in enumerate(segs):
     print("  %-28s %7.2f | %7.2f" % (n_, us(R[:, :, 6 + i].mean()), us(R[:, :, 6 + i][slow_].mean())))
 fr = R[:, :, 26].sum(); frs = R[:, :, 26][slow_].sum()
-if fr > 0: print("friction-slot visits with zero bound and zero impulse in every lane of the wavefront (a skip would be value-exact): %.1f %% of all, %.1f %% in the slowest 1 %% of the wavefronts" % (
+if "SOLO_SWEEP_STATS" in os.environ.get("SOLORL_BUILD_DEFINES", "") and fr > 0:
+    its = R[:, :, 26] / np.maximum(R[:, :, 27], 1)          # mean sweeps per solve of each wavefront and launch
+    print("sweeps per solve as the WAVEFRONT runs them (until its four envs are done): mean %.1f  median %.1f  p90 %.1f; share of wavefronts whose solves all ran the 50: %.1f %%; slowest 1 %% of the wavefronts: mean %.1f" % (
+        its[R[:, :, 27] > 0].mean(), np.median(its[R[:, :, 27] > 0]), np.percentile(its[R[:, :, 27] > 0], 90), 100.0 * (its >= 49.99).mean(), its[slow_].mean()))
+elif fr > 0: print("friction-slot visits with zero bound and zero impulse in every lane of the wavefront (a skip would be value-exact): %.1f %% of all, %.1f %% in the slowest 1 %% of the wavefronts" % (
     100.0 * R[:, :, 27].sum() / max(fr, 1), 100.0 * R[:, :, 27][slow_].sum() / max(frs, 1)))
 phases = ["sin/cos", "collision front", "legs (4 lanes)", "leg sum", "base solve (leader)", "leg rates", "row finish", "PGS sweep", "integrate"]
 print("phases of the sub-steps, summed over a step's %d sub-steps (us; mean over all wavefronts | over the slowest 1 %%; timing build drains the memory counters at every stamp):" % c.frame_skip)
