@@ -1693,7 +1693,10 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       T hi = T(0);
       if constexpr (fric) {   // impulse of this contact's normal row: normal slot c/2, half c&1
         constexpr int c = i - LIM - NNS;
-        hi = (half == (c & 1)) ? lm[LIM + (c >> 1)] : lmo[c >> 1];
+        // fp32: one DPP broadcast from the lane that owns the normal row (row_newbcast: lane 0 of the team for even contacts, lane 8 for odd
+        // ones) instead of a select between the own impulse and a running copy of the partner's (one add per normal slot and four registers less)
+        if constexpr (sizeof(T) == 4) hi = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lm[LIM + (c >> 1)]), 0x150 + 8 * (c & 1), 0xF, 0xF, true));
+        else hi = (half == (c & 1)) ? lm[LIM + (c >> 1)] : lmo[c >> 1];
       }
       auto clampb = [&](T x) -> T {
         if constexpr (!fric) return x > T(0) ? x : T(0);
@@ -1713,7 +1716,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       if constexpr (EXIT) viol = viol || (fabs(del) > th[i]);
       lm[i] = sv;
       const T delx = half_swap(del);
-      if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] += delx;
+      if constexpr (sizeof(T) != 4 && i >= LIM && i < LIM + NNS) lmo[i - LIM] += delx;
       a01 = fm(X01[i], P2{delx, delx}, fm(B01[i], P2{del, del}, a01));
       a2 = fm(X2[i], delx, fm(B2[i], del, a2));
       dpre = dnext; delp = del; delxp = delx;
