@@ -1127,14 +1127,18 @@ SNI void phase_integrate(CH ch, const PhysParams<T> pp, T* lam_prev, unsigned ns
 // null rows at the unused positions (all-zero, decided by the sweep's set-up from the team's row counts).
 // The finished rows stay where they were parked (RowLds core, dense solver index r <-> position by pos_of /
 // row_of), rewritten IN PLACE by phase_finish_team as the 20-value record the sweep needs:
-//   [0..5] J'_base  [6..8] J'_leg  [9..14] B~_base  [15..17] B~_leg  [18] rhs'  [19] leg id
+//   [2e] J'_e  [2e+1] B~_e  for the components e = 0..5 (base) and 6..8 (the row's leg)   [18] rhs'  [19] leg id
+//   (round 3: J' and B~ interleaved -- the sweep's set-up reads a lane's pair with one 64-bit LDS read)
 // Friction rows are stored in units of their contact's mu (lambda~ = lambda/mu, J' = J/mu, B~ = mu B) and every row
 // is pre-scaled by 1/diag, so the sweep needs neither mu nor 1/diag.  (Round 1 expanded every row into a separate
 // 38-value record with explicit zeros for the other legs' components: 15.8 KB of the 34.6 KB per workgroup, which
 // held the kernel at one wavefront per SIMD; now 18.4 KB -> 8 workgroups per CU, two wavefronts per SIMD.)
 //   lam  [TR][4]       impulses by position (warm start in, result out)
 //   bc   [4][BC]       base-solve broadcast block (Lam 36, u*_base 6, leg rates 12, a0 6)
-enum { E_JB = 0, E_JL = 6, E_BB = 9, E_BL = 15, E_RHS = 18, E_LEG = 19 };
+// (J', B~) of component e interleaved at 2e, 2e+1 (e = 0..5 base, 6..8 leg): the sweep's set-up reads a lane's pair with one 64-bit LDS read
+enum { E_RHS = 18, E_LEG = 19 };
+constexpr int E_J(int e) { return 2 * e; }
+constexpr int E_B(int e) { return 2 * e + 1; }
 template <typename T, typename LDS> struct TeamRows {
   static_assert(LIM_SLOT_ROWS == 2 && MAX_LIMITS <= LIM_SLOT_ROWS + MAX_CONTACTS && MAX_CONTACTS % 2 == 0, "slot map below assumes one limit slot and paired normals");
   static constexpr int NPOS0 = 2, FPOS0 = NPOS0 + MAX_CONTACTS;              // first normal / friction position
@@ -1458,10 +1462,10 @@ SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) 
     const T isB = rcp_fast(sB);
     const T sJ = dinv * isB;
     T o[ROW_CORE];
-    o[E_JB + 0] = c[0] * sJ; o[E_JB + 1] = c[1] * sJ; o[E_JB + 2] = c[2] * sJ; o[E_JB + 3] = c[3] * sJ; o[E_JB + 4] = c[4] * sJ; o[E_JB + 5] = c[5] * sJ;
-    o[E_JL + 0] = c[6] * sJ; o[E_JL + 1] = c[7] * sJ; o[E_JL + 2] = c[8] * sJ;
-    o[E_BB + 0] = W.a.x * sB; o[E_BB + 1] = W.a.y * sB; o[E_BB + 2] = W.a.z * sB; o[E_BB + 3] = W.l.x * sB; o[E_BB + 4] = W.l.y * sB; o[E_BB + 5] = W.l.z * sB;
-    o[E_BL + 0] = c[15] * sB; o[E_BL + 1] = c[16] * sB; o[E_BL + 2] = c[17] * sB;
+#pragma unroll
+    for (int e = 0; e < 9; e++) o[E_J(e)] = c[e] * sJ;                       // J': base 0..5, leg 6..8
+    o[E_B(0)] = W.a.x * sB; o[E_B(1)] = W.a.y * sB; o[E_B(2)] = W.a.z * sB; o[E_B(3)] = W.l.x * sB; o[E_B(4)] = W.l.y * sB; o[E_B(5)] = W.l.z * sB;
+    o[E_B(6)] = c[15] * sB; o[E_B(7)] = c[16] * sB; o[E_B(8)] = c[17] * sB;
     o[E_RHS] = rhs * isB;               // finish_row's rhs already carries 1/diag
     o[E_LEG] = T(leg);
     lds.store_core(r, o);
@@ -1540,25 +1544,26 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // Lane h of a half holds accumulator components h, h + 8 and (h < 2) 16 + h of [w(6), y_leg0..3(12)].  Where they
   // sit in a finished record (TeamRows): component c < 6 -> base element c; c >= 6 -> leg (c-6)/3, joint (c-6)%3,
   // present only in rows of that leg.
-  const int eU = h;                                   // comp h: base 0..5 | leg 0 joints 0,1 (J' at E_JL = 6: same index)
+  const int eU = h;                                   // comp h: base 0..5 | leg 0 joints 0,1 (component index 6, 7)
   const int legU = h < 6 ? -1 : 0;                    // -1: every row
-  const int eV = E_JL + (h + 2) % 3, legV = (h + 2) / 3;
-  const int eW = E_JL + 1 + h, legW = h < 2 ? 3 : -2; // -2: no row (the zero pair)
-  constexpr int dJB = E_BB - E_JB;                    // J' element -> B~ element (base: +9, leg: +9 as well)
-  static_assert(E_BL - E_JL == dJB, "record layout");
+  const int eV = 6 + (h + 2) % 3, legV = (h + 2) / 3;
+  const int eW = h < 2 ? 7 + h : 8, legW = h < 2 ? 3 : -2;   // -2: no row (the zero pair; the lane reads a valid component and discards it)
   // element e of parked row r sits at r * ROWB + eoff(e): the lane's six element offsets are computed once, a read is one add away from its
   // row base (written as one expression per read the compiler rebuilt the whole index arithmetic each time: 35 instructions per slot for 13 reads)
   constexpr unsigned ROWB = (unsigned)LDS::NCH * LN * 16u;
   auto eoff = [&](int e) -> unsigned { return (unsigned)(e / LDS::PER) * (LN * 16u) + (unsigned)(e % LDS::PER) * SZ + (unsigned)col * 16u; };
-  const unsigned kU = eoff(eU), kUB = eoff(eU + dJB), kV = eoff(eV), kVB = eoff(eV + dJB), kW = eoff(eW), kWB = eoff(eW + dJB);
+  using P2 = T __attribute__((ext_vector_type(2)));
+  static_assert(LDS::PER % 2 == 0, "a (J', B~) pair lies inside one 16-byte chunk");
+  const unsigned kU = eoff(E_J(eU)), kV = eoff(E_J(eV)), kW = eoff(E_J(eW));            // the lane's (J', B~) pairs: 8-byte aligned
+  const unsigned kUB = eoff(E_B(eU)), kVB = eoff(E_B(eV)), kWB = eoff(E_B(eW));
   const unsigned kLEG = eoff(E_LEG), kRHS = eoff(E_RHS);
   auto rd = [&](unsigned rb, unsigned k) -> T { return *reinterpret_cast<const T*>(solo_smem + (rb + k)); };
+  auto rd2 = [&](unsigned rb, unsigned k) -> P2 { return *reinterpret_cast<const P2*>(solo_smem + (rb + k)); };
   // all arrays below are indexed by the sweep index i.  The B~ / X~ columns of accumulator components 0 and 1 are kept as
   // explicit 2-vectors (v_pk_fma_f32 on fp32; the translation unit is built with -fno-slp-vectorize, so what is packed
   // is exactly what is written here -- left to itself the vectoriser paired unrelated multiplies of the slot's dependency
   // chain and split its fused multiply-adds).  Per slot: 3 fma + 3 DPP adds (next slot's J'.acc), 2 fma + 1 sub + clamp + sub
   // + swap + fma + clamp + sub + swap (the row pair), 2 packed + 2 scalar fma (accumulators) = 21-22 VALU instructions.
-  using P2 = T __attribute__((ext_vector_type(2)));
   auto fm = [](auto a, auto b, auto c) { return __builtin_elementwise_fma(a, b, c); };
   T J0[n], J1[n], J2[n], B2[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
   P2 B01[n], X01[n];
@@ -1589,7 +1594,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       const unsigned bo = __umul24((unsigned)ro, ROWB), bx = __umul24((unsigned)rx, ROWB);   // record address = row base + the lane's element offset (24-bit multiply: full rate)
       lego[i] = rd(bo, kLEG);
       if constexpr (!fr) legx[i] = rd(bx, kLEG); else legx[i] = T(0);
-      ju[i] = rd(bo, kU); bu[i] = rd(bo, kUB); jv[i] = rd(bo, kV); bv[i] = rd(bo, kVB); jw[i] = rd(bo, kW); bw[i] = rd(bo, kWB);
+      { const P2 u = rd2(bo, kU), v = rd2(bo, kV), w = rd2(bo, kW);       // (J', B~) of the lane's three components: one 64-bit read each
+        ju[i] = u.x; bu[i] = u.y; jv[i] = v.x; bv[i] = v.y; jw[i] = w.x; bw[i] = w.y; }
       xu[i] = rd(bx, kUB); xv[i] = rd(bx, kVB); xw[i] = rd(bx, kWB);
       rhs_[i] = rd(bo, kRHS);
       if constexpr (EXIT) th[i] = lds.A(ro, LDS::A_LAM);
