@@ -45,7 +45,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0   # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32, 2 cycles each (a LONE wave sustains 4)
 REPEATS = 5
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+EXIT_WATCHDOG = 3               # --strict: exit code when the watchdog cut the auxiliary legs short (the headline line is out by then)
 
 
 def algorithmic_bytes_per_env_step(A, S, C, O, hist_state, n_dr=5, n_counters=2):
@@ -65,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--leg-timeout", type=int, default=420, help="watchdog (s) over the auxiliary legs (PPO loop, fp64, CPU baseline): the headline line is printed without them if they hang")
     ap.add_argument("--ppo-steps", type=int, default=400, help="rollout length of the PPO-loop leg (0 = skip); README: num_steps = episode_length")
     ap.add_argument("--ppo-epoch", type=int, default=5, help="PPO epochs of that leg (README: 5)")
+    ap.add_argument("--strict", action="store_true", help="exit with code %d (instead of 0) when the watchdog had to cut an auxiliary leg short; the JSON line "
+                    "says so either way (aux_legs_complete)" % EXIT_WATCHDOG)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: all ranks use cuda:0 and the gloo backend (numbers are meaningless)")
     return ap.parse_args(argv)
@@ -146,12 +149,52 @@ def cpu_baseline(cfg, budget_s=12.0):
     one_64 = run(1, 64, budget_s * 0.2)
     one_4096 = run(1, 4096, budget_s * 0.35)
     return {"value": all_4096["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "fp64 oracle, %d Solo12-walk envs x %d control steps x 5 repetitions (median), random policy, OpenMP over envs, %d threads"
-                      % (4096, all_4096["steps_per_repetition"], cores),
+            "sample": "fp64 oracle, %d Solo12-walk envs x %d control steps x 5 repetitions (median), random policy, OpenMP over envs, %d threads; "
+                      "every reset inside the sample runs the reference's LIVE settle (5-11 zero-torque control steps, baseEnv.py:79-80), which the GPU "
+                      "engine replaces by a snapshot copy: at this workload's stationary episode length (~23 steps) that is about a third more "
+                      "physics per env-step than the GPU line does" % (4096, all_4096["steps_per_repetition"], cores),
             "protocol": "BASELINE.md section 3: 50 warm-up env-steps, >= 2000 measured env-steps, median of 5",
             "all_cores": {"envs_4096": all_4096, "envs_64": all_64},
             "single_thread": {"envs_4096": one_4096, "envs_64": one_64},
             "thread_scaling_4096": all_4096["value"] / one_4096["value"]}
+
+
+class LineGuard:
+    """Guarantees the ONE JSON line.  Every leg after the headline measurement is auxiliary; a leg that HANGS (e.g. a collective of
+    the PPO leg on a multi-GPU node) cannot be caught by try/except, so a timer prints the headline with the legs finished so far
+    (`aux_legs_complete: false`, the unfinished leg carries an error entry) and every rank leaves through os._exit -- no collective
+    is waited for.  Exit code then: 0, or EXIT_WATCHDOG with --strict (the caller decides whether a partial line is acceptable)."""
+
+    def __init__(self, rank, timeout_s, strict, build_line, ppo_requested, exit_fn=os._exit):
+        import threading
+        self.rank, self.timeout_s, self.strict, self.build_line, self.exit_fn = rank, timeout_s, strict, build_line, exit_fn
+        self.state = {"f64": None, "ppo": {"error": "not run"} if ppo_requested else None, "cpu": None, "printed": False}
+        self.timer = threading.Timer(timeout_s, self.on_timeout)
+        self.timer.daemon = True
+
+    def start(self):
+        self.timer.start()
+
+    def emit(self, extra_note=None):
+        if self.state["printed"] or self.rank != 0:
+            return
+        self.state["printed"] = True
+        line = self.build_line(self.state)
+        line["aux_legs_complete"] = extra_note is None
+        if extra_note:
+            line["note"] = extra_note
+        print(json.dumps(line), flush=True)
+
+    def on_timeout(self):
+        ppo = self.state["ppo"]
+        if ppo is not None and ppo.get("error") == "not run":
+            self.state["ppo"] = {"error": "the PPO leg did not finish within %d s (watchdog); headline unaffected" % self.timeout_s}
+        self.emit("auxiliary legs cut short by the watchdog")
+        self.exit_fn(EXIT_WATCHDOG if self.strict else 0)
+
+    def finish(self):
+        self.timer.cancel()
+        self.emit()
 
 
 def ppo_leg(env, dev, world, T, epochs):
@@ -182,39 +225,59 @@ def ppo_leg(env, dev, world, T, epochs):
     def iteration():
         sync(); t0 = time.perf_counter()
         roll()
-        torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
+        torch.cuda.synchronize(); t1 = time.perf_counter()
         with torch.no_grad():
             nv = pol.get_value(st.obs[-1])
         st.compute_returns(nv, True, 0.99, 0.95)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
         agent.update(st)
         st.reset()
         sync()
-        return t_roll, time.perf_counter() - t0
+        t3 = time.perf_counter()
+        return t1 - t0, t3 - t0, t2 - t1, t3 - t2
 
     iteration()                     # captures both graphs (and trains one step)
     runs = []
     for _ in range(3):              # median of three timed iterations (max over ranks each)
-        t_roll, t_all = iteration()
+        t_roll, t_all, t_ret, t_upd = iteration()
         if world > 1:
-            tt = torch.tensor([t_roll, t_all], device=dev, dtype=torch.float64)
+            tt = torch.tensor([t_roll, t_all, t_ret, t_upd], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_roll, t_all = tt.tolist()
-        runs.append((t_all, t_roll))
+            t_roll, t_all, t_ret, t_upd = tt.tolist()
+        runs.append((t_all, t_roll, t_ret, t_upd))
     runs.sort()
-    t_all, t_roll = runs[1]
+    t_all, t_roll, t_ret, t_upd = runs[1]
     out = {"env_steps_per_s": world * N * T / t_all, "rollout_env_steps_per_s": world * N * T / t_roll, "rollout_steps": T,
+           "rollout_ms": 1e3 * t_roll, "returns_ms": 1e3 * t_ret, "update_ms": 1e3 * t_upd,
            "iterations_timed": 3, "statistic": "median iteration", "iteration_ms": [1e3 * r[0] for r in runs],
-           "allreduce_in_graph": (not getattr(agent, "_split", True)) if world > 1 else None,
+           "allreduce_in_graph": bool(getattr(agent, "allreduce_in_graph", False)) if world > 1 else None,
            "ppo_epoch": epochs, "mini_batches_per_epoch": (T * N) // mb, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
            "note": "policy act (solorl_policy_act) + env.step writing into the rollout storage per step, then GAE + PPO epochs (solorl_ppo_grad_stage1/2 + clip + Adam per mini-batch); rollout and mini-batch step replayed from HIP graphs"}
-    if world > 1:                   # the collective of the data-parallel PPO step, timed on its own
+    if world > 1:                   # the collective of the data-parallel PPO step, timed on its own -- on SCRATCH tensors of the
+        from solorl_amd.ppo import dist as D      # bucket's size (zeros: 50 summed all-reduces of live gradients would overflow)
+        from solorl_amd.ppo.graphs import probe_captured_allreduce
         reps = 50
-        sync(); t0 = time.perf_counter()
-        for _ in range(reps):
-            agent.bucket.all_reduce_sum()
-        sync()
-        out["grad_allreduce"] = {"bytes": agent.bucket.flat.numel() * 4, "us_per_call": 1e6 * (time.perf_counter() - t0) / reps,
-                                 "calls_per_update": out["optimizer_steps"], "backend": dist.get_backend()}
+
+        def eager_us(numel):
+            x = torch.zeros(numel, device=dev)
+            dist.all_reduce(x)
+            sync(); t0 = time.perf_counter()
+            for _ in range(reps):
+                dist.all_reduce(x, op=dist.ReduceOp.SUM)
+            sync()
+            return 1e6 * (time.perf_counter() - t0) / reps
+
+        nb = agent.bucket.flat.numel()
+        out["grad_allreduce"] = {"bytes": nb * 4, "us_per_call": eager_us(nb), "us_per_call_8_bytes": eager_us(2),
+                                 "calls_per_update": out["optimizer_steps"], "backend": dist.get_backend(), "rccl_env": D.rccl_env(),
+                                 "note": "eager all_reduce(sum) of a scratch tensor of the bucket's size; beside it the same call on 8 bytes: "
+                                         "equal latencies = the bucket is latency-bound, whatever algorithm RCCL's tuner picked"}
+        if dist.get_backend() == "nccl":          # one execution of a CAPTURED all-reduce of the real bucket size (opt-in for training)
+            try:
+                ok, sec = probe_captured_allreduce(dev, nb, replays=8, time_it=True)
+                out["grad_allreduce"]["captured_probe"] = {"ok": ok, "us_per_replay": None if sec is None else 1e6 * sec, "replays_checked": 8}
+            except Exception as ex:
+                out["grad_allreduce"]["captured_probe"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return out
 
 
@@ -246,6 +309,8 @@ def main(argv=None):
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
+            from solorl_amd.ppo.dist import pin_rccl_from_env
+            pin_rccl_from_env()             # SOLORL_RCCL_ALGO / SOLORL_RCCL_PROTO -> NCCL_ALGO / NCCL_PROTO, before the communicator exists
             dist.init_process_group("nccl", device_id=dev)
 
     N, K = args.envs_per_gpu, args.steps
@@ -322,7 +387,8 @@ def main(argv=None):
     elapsed, dev_elapsed = walls[mid], devs[mid]
     k_avg = 1e3 * dev_elapsed / K                 # ms per launch inside the timed window (graph: includes the ~1 us node gaps)
 
-    def build_line(f64, ppo):
+    def build_line(state):
+        f64, ppo = state["f64"], state["ppo"]
         A, S, O, D = env.act_dim, 37, env.obs_dim, cfg.state_dim
         bytes_step = algorithmic_bytes_per_env_step(A=A, S=S, C=48, O=O, hist_state=D)
         achieved = bytes_step * N / (k_avg * 1e-3) / 1e9
@@ -336,7 +402,8 @@ def main(argv=None):
                        "task": "walk", "envs_per_gpu": N, "frame_skip": 4, "episode_length": EPISODE_LENGTH,
                        "num_history_stack": 1, "control": "torque", "parallelism": "env-sharded x%d" % world, "launch": launch,
                        "solver": {"iterations_max": cfg.solver_iterations, "residual_threshold": cfg.solver_residual_threshold,
-                                  "warmstart": cfg.warmstart, "note": "PyBullet defaults: 50 iterations, solverResidualThreshold 1e-7; no multibody warm start"},
+                                  "warmstart": cfg.warmstart, "friction_model": "cone" if cfg.friction_model else "pyramid", "erp": cfg.erp, "contact_erp": cfg.contact_erp,
+                                  "note": "PyBullet defaults [K]: 50 iterations, solverResidualThreshold 1e-7, no multibody warm start, implicit friction cone, erp 0.2 / contactERP 0.08"},
                        "engine": {k: env.get_property(k) for k in ("lanes_per_env", "sweep_variant", "max_contacts", "max_limit_rows")},
                        "burn_in_steps": burn_in, "repeats": REPEATS, "statistic": "median of %d repeats of exactly %d steps" % (REPEATS, K)},
             "repeats_ms_per_step": [1e3 * w / K for w in walls],
@@ -380,30 +447,10 @@ def main(argv=None):
         return out
 
     ppo = None
-    # From here on every leg is auxiliary to the headline measurement above.  A leg that HANGS (e.g. a collective of the PPO leg on a
-    # multi-GPU node) cannot be caught by try/except, so a watchdog guarantees the line: when it fires, rank 0 prints the headline with
-    # the legs finished so far and every rank leaves (os._exit: no collective is waited for).
-    import threading
-    state = {"f64": None, "ppo": {"error": "not run"} if args.ppo_steps > 0 else None, "printed": False}
-
-    def emit(extra_note=None):
-        if state["printed"] or rank != 0:
-            return
-        state["printed"] = True
-        line = build_line(state["f64"], state["ppo"])
-        if extra_note:
-            line["note"] = extra_note
-        print(json.dumps(line), flush=True)
-
-    def on_timeout():
-        if state["ppo"] is not None and state["ppo"].get("error") == "not run":
-            state["ppo"] = {"error": "the PPO leg did not finish within %d s (watchdog); headline unaffected" % args.leg_timeout}
-        emit("auxiliary legs cut short by the watchdog")
-        os._exit(0)
-
-    watchdog = threading.Timer(args.leg_timeout, on_timeout)
-    watchdog.daemon = True
-    watchdog.start()
+    # From here on every leg is auxiliary to the headline measurement above (LineGuard: the line is printed even if one hangs).
+    guard = LineGuard(rank, args.leg_timeout, args.strict, build_line, args.ppo_steps > 0)
+    state = guard.state
+    guard.start()
     # the same workload on the engine's fp64 instantiation (the reference's arithmetic type), single repeat of <= 100 steps
     f64 = None
     if not args.no_f64:
@@ -414,15 +461,39 @@ def main(argv=None):
             e64.reset()
             for t in range(burn_in):
                 e64.step_inplace(acts[t % R])
-            K64 = min(K, 100)
-            barrier(); t0 = time.perf_counter()
-            for t in range(K64):
-                e64.step_inplace(acts[t % R])
-            barrier(); el64 = time.perf_counter() - t0
-            if world > 1:
-                t_ = torch.tensor([el64], device=dev, dtype=torch.float64); dist.all_reduce(t_, op=dist.ReduceOp.MAX); el64 = float(t_.item())
-            f64 = {"value": world * N * K64 / el64, "unit": "env-steps/s", "ms_per_step": 1e3 * el64 / K64, "steps": K64, "dtype": "f64",
-                   "launch": "eager", "note": "step_kernel_team<double,solo12>, same workload and burn-in; parity-tested against the oracle to rounding"}
+            K64 = 100               # fixed, whatever --steps says: the documented fp64 figure is the one the driver's command prints
+            launch64 = "hip_graph"
+            try:
+                torch.cuda.synchronize()
+                g64 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g64, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
+                    for t in range(K64):
+                        e64.step_inplace(acts[t % R])
+            except Exception:
+                g64, launch64 = None, "eager"
+            if not all_ranks(g64 is not None):
+                g64, launch64 = None, "eager"
+
+            def run64():
+                if g64 is not None:
+                    g64.replay()
+                else:
+                    for t in range(K64):
+                        e64.step_inplace(acts[t % R])
+
+            run64()                 # first replay untimed
+            els = []
+            for _ in range(3):
+                barrier(); t0 = time.perf_counter()
+                run64()
+                barrier(); el = time.perf_counter() - t0
+                if world > 1:
+                    t_ = torch.tensor([el], device=dev, dtype=torch.float64); dist.all_reduce(t_, op=dist.ReduceOp.MAX); el = float(t_.item())
+                els.append(el)
+            el64 = sorted(els)[1]
+            f64 = {"value": world * N * K64 / el64, "unit": "env-steps/s", "ms_per_step": 1e3 * el64 / K64, "steps": K64, "repeats": 3, "dtype": "f64",
+                   "launch": launch64, "statistic": "median of 3 repeats of exactly 100 steps after the same burn-in",
+                   "note": "step_kernel_team<double,solo12>, same workload and burn-in; parity-tested against the oracle to rounding"}
             e64.close()
         except Exception as ex:
             f64 = {"error": "%s: %s" % (type(ex).__name__, ex)}
@@ -438,13 +509,11 @@ def main(argv=None):
             ppo = ppo if (ppo and "error" in ppo) else {"error": "the PPO leg failed on another rank"}     # any further collective
     state["ppo"] = ppo
 
-    state["cpu"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         state["cpu"] = cpu_baseline(cfg)
-    watchdog.cancel()
-    emit()
+    guard.finish()
     if world > 1:                         # the line is out: a rank whose process group is unhealthy must not keep the job from ending
-        bye = threading.Timer(60, lambda: os._exit(0))
+        bye = threading.Timer(60, lambda: os._exit(EXIT_WATCHDOG if args.strict else 0))
         bye.daemon = True
         bye.start()
         try:

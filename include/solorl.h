@@ -50,6 +50,11 @@ enum { SOLORL_ROBOT_SOLO8 = 0, SOLORL_ROBOT_SOLO12 = 1 };
 enum { SOLORL_TASK_STAND = 0, SOLORL_TASK_WALK = 1, SOLORL_TASK_POINTGOAL = 2 };
 enum { SOLORL_CONTROL_TORQUE = 0, SOLORL_CONTROL_PD = 1 };
 enum { SOLORL_PRECISION_F32 = 0, SOLORL_PRECISION_F64 = 1 };
+enum { SOLORL_FRICTION_PYRAMID = 0, SOLORL_FRICTION_CONE = 1 };
+
+/* Bumped whenever a struct of this header changes layout or meaning; solorl_abi_version() returns the value the library was built with
+ * and a binding compares the two before its first call (a caller built against another layout would hand over short structs). */
+#define SOLORL_ABI_VERSION 4
 
 enum {
   SOLORL_OK = 0,
@@ -76,6 +81,12 @@ typedef struct solorl_config {
   int32_t disable_termination; /* parity runs: never set done */
   int32_t precision;        /* SOLORL_PRECISION_*: arithmetic type of the HIP engine */
   int32_t use_treadmill;    /* config 'use_treadmill' (simulation.py:24-26,45-77): friction strip, see treadmill_* below */
+  int32_t friction_model;   /* SOLORL_FRICTION_*: how the two friction rows of a contact are bounded by mu * normal impulse.
+                             * PYRAMID: each row clamped to +-mu lambda_n on its own, Gauss-Seidel between the two (rounds 1-3).
+                             * CONE: Bullet's implicit friction cone [K] -- btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, the
+                             * path PyBullet takes unless setPhysicsEngineParameter(enableConeFriction=0) (the reference never calls it,
+                             * simulation.py:13-35): both rows' unclamped sums against the same delta-velocities, the pair projected
+                             * radially onto the disc of radius mu lambda_n.  DESIGN.md section 3 ([K] ledger) has the measured difference. */
   double kp, kd;            /* config 'gains' (configs/basic_pd.yaml:6) */
   double max_torque;        /* solo.py:53 max_joint_torque = 3 */
   double sim_dt;            /* solo.py:22 scene_timestep = 1/240 */
@@ -106,6 +117,10 @@ typedef struct solorl_config {
    * Measured on the oracle: with warmstart = 0 the exit leaves a PD stance stable over 1000 control steps
    * at a mean of ~12 sweeps; with warmstart = 0.85 it does not -- the pair (0, 1e-7) is what Bullet's multibody solver runs [K]. */
   double solver_residual_threshold;
+  /* Error reduction of the CONTACT rows (Bullet: btContactSolverInfo::m_erp2, read by setupMultiBodyContactConstraint); `erp` above is
+   * m_erp, which the joint-limit rows use.  PyBullet's physics server sets m_erp2 = 0.08 beside m_erp = 0.2 [K]; rounds 1-3 used one
+   * value (0.2) for both.  DESIGN.md section 3 ([K] ledger) has the measured difference. */
+  double contact_erp;
 } solorl_config;
 
 /* Struct-of-arrays info block (replaces the per-env dicts of baseEnv.py:62-66).  Every pointer is
@@ -282,6 +297,7 @@ int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* 
 
 const char* solorl_last_error(void);
 const char* solorl_version(void);
+int solorl_abi_version(void);   /* SOLORL_ABI_VERSION of the built library */
 
 #ifdef __cplusplus
 }

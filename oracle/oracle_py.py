@@ -35,9 +35,13 @@ def lib():
                      "oracle_increment_curriculum", "oracle_get_state", "oracle_set_state", "oracle_set_threads",
                      "oracle_substep", "oracle_mass_matrix", "oracle_forward_dynamics", "oracle_energy_momentum",
                      "oracle_prim_points", "oracle_last_lambda", "oracle_philox", "oracle_euler_from_quat", "oracle_set_caps",
-                     "oracle_set_contact_model", "oracle_last_counts"):
+                     "oracle_set_contact_model", "oracle_last_counts", "oracle_iteration_histogram"):
             getattr(L, name).restype = None
         L.oracle_increment_curriculum.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_set_option.restype = C.c_int
+        L.oracle_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.oracle_last_residual.restype = C.c_double
+        L.oracle_last_residual.argtypes = [C.c_void_p, C.c_int]
         L.oracle_last_iterations.restype = C.c_int
         L.oracle_last_iterations.argtypes = [C.c_void_p, C.c_int]
         _LIB = L
@@ -125,6 +129,9 @@ class Oracle:
     def last_iterations(self, i=0):
         return int(self.L.oracle_last_iterations(self.h, int(i)))
 
+    def last_residual(self, i=0):
+        return float(self.L.oracle_last_residual(self.h, int(i)))
+
     def set_caps(self, max_contacts=0, max_limits=0):
         """engine emulation (0 = uncapped, the default): see oracle_set_caps"""
         self.L.oracle_set_caps(self.h, int(max_contacts), int(max_limits))
@@ -132,6 +139,17 @@ class Oracle:
     def set_contact_model(self, model):
         """0 = analytic primitives (the engine's model), 1 = hull manifolds (Bullet's scheme [K6])"""
         self.L.oracle_set_contact_model(self.h, int(model))
+
+    def set_option(self, name, value):
+        """[K] ledger switches that are not solorl_config fields (oracle/solo_oracle.h oracle_set_option)"""
+        if self.L.oracle_set_option(self.h, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def iteration_histogram(self, clear=False):
+        """sub-steps with constraint rows, by the number of PGS sweeps they ran (bin = sweeps, 128 bins), summed over envs"""
+        o = np.zeros(128, np.int64)
+        self.L.oracle_iteration_histogram(self.h, _p(o), int(bool(clear)))
+        return o
 
     def last_counts(self, i=0):
         """(contact points found, solved, joint-limit candidates, solved) of env i's last sub-step"""

@@ -29,7 +29,8 @@
  * lets a test impose those numbers here to measure what they cost (tests/test_oracle_caps.py) -- the parity tests run uncapped. */
 #define NPT_MAX (4 * NL_MAX)                       /* contact points: <= 4 per link in the manifold model, NP_MAX primitives otherwise */
 #define MAX_ROWS (2 * SOLORL_MAX_DOF + 3 * NPT_MAX)
-#define HULL_MARGIN 0.001 /* collision margin of URDF-imported convex hulls */
+#define HULL_MARGIN 0.001 /* collision margin of URDF-imported convex hulls; oracle_set_option("hull_margin") */
+#define ITER_HIST 128
 /* A joint-limit row exists while the joint is AT or BEYOND its limit (margin <= 0): btMultiBodyJointLimitConstraint::createConstraintRows
  * skips a row whose `penetration > 0` [K5].  (Rounds 1-2: a speculative row from 0.5 rad before the limit; ORACLE_LIMIT_WINDOW=0.5
  * restores it for the measurement in tests/test_oracle_caps.py.) */
@@ -117,6 +118,7 @@ struct oracle_env {
   double inertia[NL_MAX][6]; /* link inertia about COM in link axes: xx yy zz xy xz yz */
   solorl_env_state* st;
   double (*last_lambda)[NP_MAX];
+  double* last_resid;            /* K7 residual (max squared velocity-level change) of the last sweep of each env's last sub-step */
   int* last_iterations;          /* PGS iterations the last sub-step of each env ran (early exit, K7) */
   int* last_counts;              /* [N][4]: last sub-step's contact points before / after the cap, limit candidates before / after */
   int cap_contacts, cap_limits;  /* 0 = none (default); oracle_set_caps */
@@ -127,6 +129,16 @@ struct oracle_env {
   unsigned manifold_links;      /* model 1: bit l = link l collides through its hull manifold; links not in the mask keep their primitives (ablation hook) */
   const oracle_hull* hulls;
   struct manifold_t* man;        /* [N][NL_MAX], model 1 */
+  /* [K] ledger options (oracle_set_option; tools/k_ledger.py): each restates one Bullet default the reference inherits, so that what it
+   * would cost to have it wrong can be MEASURED.  Defaults = what the HIP engine runs (solorl_config carries the ones that became fields). */
+  int opt_friction_skip;         /* pyramid only: a friction row is not solved while its contact's normal impulse is 0 (Bullet's `if (totalImpulse > 0)`) */
+  int opt_gyro;                  /* 1 (default): gyroscopic term w x I w (btMultiBody::m_useGyroTerm) */
+  int opt_limit_split;           /* 1: a joint more than 0.04 rad beyond its limit loses the positional term (btMultiBodyJointLimitConstraint with
+                                  * m_splitImpulse on and no split-impulse pass for multibodies) and uses erp2 */
+  double opt_prim_margin;        /* collision margin added around the primitives (Bullet: 1 mm around URDF hulls; the primitives carry none) */
+  double opt_break_scale;        /* scale of every contact-breaking threshold (gContactBreakingThreshold 0.02) */
+  double opt_hull_margin;        /* manifold model: the hulls' collision margin (HULL_MARGIN) */
+  int64_t (*iter_hist)[ITER_HIST]; /* [N][ITER_HIST]: sub-steps that had rows, by the number of PGS sweeps they ran */
 };
 typedef struct manifold_t { int n; double local[4][3], worldB[4][3], dist[4], lam[4]; } manifold_t;
 static const solorl_prim_data* prim_of(const oracle_env* E, int p) { return &E->md->prims[p]; }
@@ -240,6 +252,7 @@ static void mass_and_bias(const oracle_env* E, const solorl_env_state* s, const 
     F[2] += -L->mass * E->cfg.gravity;
     m3mulv(ang, K->Iw[i], K->alb[i]);
     v3cross(t, K->w[i], Iw_w);                       /* gyroscopic term (K1) */
+    if (!E->opt_gyro) v3set(t, 0, 0, 0);
     for (int k = 0; k < 3; k++) { lin[k] = L->mass * K->acb[i][k] - F[k]; ang[k] += t[k] - T[k]; }
     for (int a = 0; a < nv; a++)
       for (int k = 0; k < 3; k++) h[a] += Jv[k][a] * lin[k] + Jw[k][a] * ang[k];
@@ -298,8 +311,10 @@ static int collide_primitives(const oracle_env* E, const solorl_env_state* s, co
   for (int p = 0; p < E->np; p++) {
     double P[3];
     if ((skip_links >> prim_of(E, p)->link) & 1u) continue;
-    const double d = prim_point(E, K, p, P);
-    if (d < prim_of(E, p)->margin) {
+    /* a collision margin m around a shape (its Minkowski sum with a sphere) lowers the support point towards the plane by m */
+    const double d = prim_point(E, K, p, P) - E->opt_prim_margin;
+    P[2] = d;
+    if (d < prim_of(E, p)->margin * E->opt_break_scale) {
       cpoint_t* c = &cp[n++];
       c->link = prim_of(E, p)->link; c->id = p; c->prim = 1; v3cpy(c->P, P); c->dist = d; c->friction = prim_of(E, p)->friction; c->lam0 = s->lambda_prev[p];
     }
@@ -321,12 +336,12 @@ static int collide_manifolds(oracle_env* E, int ei, const kin_t* K, cpoint_t* cp
     const oracle_hull* H = &E->hulls[l];
     double thr = 0, fric = 0.5;
     int have = 0;
-    for (int p = 0; p < E->np; p++) if (prim_of(E, p)->link == l) { thr = prim_of(E, p)->margin; fric = prim_of(E, p)->friction; have = 1; break; }
+    for (int p = 0; p < E->np; p++) if (prim_of(E, p)->link == l) { thr = prim_of(E, p)->margin * E->opt_break_scale; fric = prim_of(E, p)->friction; have = 1; break; }
     if (!have) {   /* links without a primitive (lower legs): threshold from the hull's own bounding sphere about the COM */
       double lo[3] = {1e9, 1e9, 1e9}, hi[3] = {-1e9, -1e9, -1e9}, c[3], hx[3];
       for (int i = 0; i < H->n; i++) for (int k = 0; k < 3; k++) { if (H->v[i][k] < lo[k]) lo[k] = H->v[i][k]; if (H->v[i][k] > hi[k]) hi[k] = H->v[i][k]; }
-      for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]) - E->md->links[l].com[k]; hx[k] = 0.5 * (hi[k] - lo[k]) + HULL_MARGIN; }
-      thr = 0.02 * (v3norm(c) + v3norm(hx)); fric = 1.0;   /* URDF <contact> friction of the lower legs is 1.0 */
+      for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]) - E->md->links[l].com[k]; hx[k] = 0.5 * (hi[k] - lo[k]) + E->opt_hull_margin; }
+      thr = 0.02 * (v3norm(c) + v3norm(hx)) * E->opt_break_scale; fric = 1.0;   /* URDF <contact> friction of the lower legs is 1.0 */
     }
     /* support vertex: lowest hull vertex in the world (plane normal +z) */
     const double* R = K->R[l];
@@ -335,10 +350,10 @@ static int collide_manifolds(oracle_env* E, int ei, const kin_t* K, cpoint_t* cp
       const double z = R[6] * H->v[i][0] + R[7] * H->v[i][1] + R[8] * H->v[i][2];
       if (z < zb) { zb = z; best = i; }
     }
-    const double dist = zb + K->o[l][2] - HULL_MARGIN;
+    const double dist = zb + K->o[l][2] - E->opt_hull_margin;
     if (dist < thr) {
       /* localA = link-frame coordinates of (vertex - margin * normal): what btManifoldResult stores as m_localPointA */
-      double down[3] = {0, 0, -HULL_MARGIN}, dl[3], loc[3], wA[3];
+      double down[3] = {0, 0, -E->opt_hull_margin}, dl[3], loc[3], wA[3];
       m3tmulv(dl, R, down);
       for (int k = 0; k < 3; k++) loc[k] = H->v[best][k] + dl[k];
       m3mulv(wA, R, loc); v3add(wA, wA, K->o[l]);
@@ -496,8 +511,14 @@ static void substep(oracle_env* E, int ei) {
     for (int k = 0; k < nv; k++) { denom += r->J[k] * r->B[k]; rel += r->J[k] * u[k]; }
     r->dinv = 1.0 / denom;
     if (i < nnormal_end) { /* limit or normal row: speculative / ERP right-hand side */
-      double pen = r->rhs, pos = 0, vel = -rel;
-      if (pen > 0) vel -= pen / dt; else pos = -pen * C->erp / dt;
+      /* Bullet keeps two error-reduction parameters: btContactSolverInfo::m_erp (non-contact rows: the joint limits, 0.2) and m_erp2
+       * (contact rows; btMultiBodyConstraintSolver::setupMultiBodyContactConstraint reads m_erp2) -- solorl_config erp / contact_erp [K] */
+      double pen = r->rhs, pos = 0, vel = -rel, erp = i < nsel_limits ? C->erp : C->contact_erp;
+      /* [K] option: btMultiBodyJointLimitConstraint::createConstraintRows takes m_erp and the combined right-hand side only while
+       * penetration > m_splitImpulsePenetrationThreshold (-0.04); deeper, the positional part goes to m_rhsPenetration, which no
+       * multibody pass ever solves */
+      if (i < nsel_limits && E->opt_limit_split && pen <= -0.04) erp = 0;
+      if (pen > 0) vel -= pen / dt; else pos = -pen * erp / dt;
       r->rhs = (pos + vel) * r->dinv;
     } else r->rhs = -rel * r->dinv;
     r->lam = 0;
@@ -511,6 +532,32 @@ static void substep(oracle_env* E, int ei) {
     double resid = 0;   /* K7: btMultiBodyConstraintSolver::solveSingleIteration's leastSquaresResidual = max (deltaImpulse / jacDiagABInv)^2 */
     for (int i = 0; i < nr; i++) {
       row_t* r = &rows[i];
+      if (r->parent >= 0 && C->friction_model == SOLORL_FRICTION_CONE) {
+        /* Bullet's implicit friction cone [K]: btMultiBodyConstraintSolver::solveSingleIteration, with SOLVER_USE_2_FRICTION_DIRECTIONS (set by
+         * btMultiBodyDynamicsWorld's constructor) and without SOLVER_DISABLE_IMPLICIT_CONE_FRICTION (PyBullet's enableConeFriction default),
+         * hands the two friction rows of a contact to resolveConeFrictionConstraintRows: both unclamped sums are taken against the SAME
+         * delta-velocities (no Gauss-Seidel step between the two directions), the pair is projected radially onto the disc of radius
+         * mu * normal impulse (atan2 / sin / cos in the source: |limit sin|, |limit cos| are the projected components), both deltas are
+         * applied, and the residual entry is the SUM of the two velocity-level changes. */
+        row_t* r2 = &rows[i + 1];
+        double ja = 0, jb = 0;
+        for (int k = 0; k < nv; k++) { ja += r->J[k] * dV[k]; jb += r2->J[k] * dV[k]; }
+        double sa = r->lam + (r->rhs - ja * r->dinv), sb = r2->lam + (r2->rhs - jb * r2->dinv);
+        const double lim = r->mu * rows[r->parent].lam;
+        if (sa * sa + sb * sb >= lim * lim) {
+          const double ang = atan2(sa, sb), ca = fabs(lim * sin(ang)), cb = fabs(lim * cos(ang));
+          if (sa < -ca) sa = -ca; else if (sa > ca) sa = ca;
+          if (sb < -cb) sb = -cb; else if (sb > cb) sb = cb;
+        }
+        const double da = sa - r->lam, db = sb - r2->lam;
+        r->lam = sa; r2->lam = sb;
+        for (int k = 0; k < nv; k++) dV[k] += r->B[k] * da + r2->B[k] * db;
+        { double dvel = da / r->dinv + db / r2->dinv; if (dvel * dvel > resid) resid = dvel * dvel; }
+        i++;
+        continue;
+      }
+      /* [K] option: the pyramid branch of solveSingleIteration solves a friction row only `if (totalImpulse > 0)` */
+      if (r->parent >= 0 && E->opt_friction_skip && !(rows[r->parent].lam > 0)) continue;
       double jdv = 0;
       for (int k = 0; k < nv; k++) jdv += r->J[k] * dV[k];
       double delta = r->rhs - jdv * r->dinv, sum = r->lam + delta, lo = 0, hi = 1e30;
@@ -520,11 +567,12 @@ static void substep(oracle_env* E, int ei) {
       for (int k = 0; k < nv; k++) dV[k] += r->B[k] * delta;
       { double dvel = delta / r->dinv; if (dvel * dvel > resid) resid = dvel * dvel; }
     }
-    E->last_iterations[ei] = it + 1;
+    E->last_iterations[ei] = it + 1; E->last_resid[ei] = resid;
     /* solveGroupCacheFriendlyIterations: stop once the residual is within solverResidualThreshold (PyBullet default 1e-7) */
     if (C->solver_residual_threshold > 0 && resid <= C->solver_residual_threshold) break;
   }
   if (nr == 0) E->last_iterations[ei] = 0;
+  else { int b = E->last_iterations[ei]; E->iter_hist[ei][b < ITER_HIST ? b : ITER_HIST - 1]++; }
   for (int k = 0; k < nv; k++) { u[k] += dV[k]; clampv(&u[k], C->max_velocity); }
   for (int p = 0; p < NP_MAX; p++) { s->lambda_prev[p] = 0; E->last_lambda[ei][p] = 0; }
   s->contact_mask = 0;
@@ -738,8 +786,11 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   E->st = (solorl_env_state*)calloc((size_t)num_envs, sizeof *E->st);
   E->last_lambda = calloc((size_t)num_envs, sizeof *E->last_lambda);
   E->last_iterations = calloc((size_t)num_envs, sizeof *E->last_iterations);
+  E->last_resid = calloc((size_t)num_envs, sizeof *E->last_resid);
   E->last_counts = calloc((size_t)num_envs * 4, sizeof *E->last_counts);
   E->man = calloc((size_t)num_envs * NL_MAX, sizeof *E->man);
+  E->iter_hist = calloc((size_t)num_envs, sizeof *E->iter_hist);
+  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_prim_margin = 0; E->opt_break_scale = 1; E->opt_hull_margin = HULL_MARGIN;
   E->hulls = cfg->robot == SOLORL_ROBOT_SOLO12 ? ORACLE_HULLS_SOLO12 : ORACLE_HULLS_SOLO8;
   E->contact_model = 0; E->cap_contacts = 0; E->cap_limits = 0; E->manifold_links = ~0u;
   if (getenv("ORACLE_MANIFOLD_LINKS")) E->manifold_links = (unsigned)strtoul(getenv("ORACLE_MANIFOLD_LINKS"), NULL, 0);
@@ -751,8 +802,24 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   for (int i = 0; i < num_envs; i++) { E->st[i].quat[3] = 1; E->st[i].pos[2] = 0.35; E->st[i].need_reset = 1; }
   return E;
 }
-void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E->last_iterations); free(E->last_counts); free(E->man); free(E); }
+void oracle_destroy(oracle_env* E) { if (!E) return; free(E->st); free(E->last_lambda); free(E->last_iterations); free(E->last_resid); free(E->last_counts); free(E->man); free(E->iter_hist); free(E); }
 int oracle_last_iterations(const oracle_env* E, int i) { return E->last_iterations[i]; }
+double oracle_last_residual(const oracle_env* E, int i) { return E->last_resid[i]; }
+int oracle_set_option(oracle_env* E, const char* name, double v) {
+  if (!strcmp(name, "friction_skip_zero_normal")) E->opt_friction_skip = v != 0;
+  else if (!strcmp(name, "gyro")) E->opt_gyro = v != 0;
+  else if (!strcmp(name, "limit_split")) E->opt_limit_split = v != 0;
+  else if (!strcmp(name, "prim_margin")) E->opt_prim_margin = v;
+  else if (!strcmp(name, "breaking_scale")) E->opt_break_scale = v;
+  else if (!strcmp(name, "hull_margin")) E->opt_hull_margin = v;
+  else return -1;
+  return 0;
+}
+void oracle_iteration_histogram(oracle_env* E, int64_t* out /* [ITER_HIST = 128] */, int clear) {
+  memset(out, 0, sizeof(int64_t) * ITER_HIST);
+  for (int i = 0; i < E->N; i++) for (int b = 0; b < ITER_HIST; b++) out[b] += E->iter_hist[i][b];
+  if (clear) memset(E->iter_hist, 0, sizeof(*E->iter_hist) * (size_t)E->N);
+}
 void oracle_set_caps(oracle_env* E, int max_contacts, int max_limits) { E->cap_contacts = max_contacts; E->cap_limits = max_limits; }
 void oracle_set_contact_model(oracle_env* E, int model) { E->contact_model = model != 0; memset(E->man, 0, sizeof(manifold_t) * (size_t)E->N * NL_MAX); }
 void oracle_last_counts(const oracle_env* E, int i, int out[4]) { memcpy(out, &E->last_counts[4 * i], sizeof(int) * 4); }

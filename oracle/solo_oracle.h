@@ -50,6 +50,8 @@ void oracle_prim_points(const oracle_env* e, int i, double* out);
 void oracle_last_lambda(const oracle_env* e, int i, double* lambda_n /* [nprims] */);
 /* PGS iterations the last sub-step of env i ran (<= solver_iterations: early exit on the residual threshold, K7) */
 int oracle_last_iterations(const oracle_env* e, int i);
+/* the K7 residual (max over rows of the squared velocity-level change) of that solve's last sweep */
+double oracle_last_residual(const oracle_env* e, int i);
 /* Engine emulation for measurements (tests/test_oracle_caps.py): solve at most max_contacts contact points (the deepest) and
  * max_limits joint-limit rows (the most violated) per sub-step, as the HIP engine's slot count does; 0 = no cap (default: the
  * oracle, like Bullet, has none). */
@@ -58,6 +60,12 @@ void oracle_set_caps(oracle_env* e, int max_contacts, int max_limits);
  * collision mesh against the plane, one new point per step into a persistent <= 4-point manifold (oracle/hull_data.h).
  * Clears the manifolds.  (Env var ORACLE_CONTACT_MODEL=1 selects it at create.) */
 void oracle_set_contact_model(oracle_env* e, int model);
+/* [K] ledger options (tools/k_ledger.py): Bullet defaults the reference inherits that are NOT solorl_config fields,
+ * switchable on the oracle so that their effect can be measured.  Names: "friction_skip_zero_normal" (0), "gyro" (1), "limit_split" (0),
+ * "prim_margin" (0 m), "breaking_scale" (1), "hull_margin" (0.001 m).  Returns 0, or -1 for an unknown name. */
+int oracle_set_option(oracle_env* e, const char* name, double value);
+/* sub-steps that had constraint rows, by the number of PGS sweeps they ran (128 bins, summed over envs; clear != 0 zeroes the counts) */
+void oracle_iteration_histogram(oracle_env* e, int64_t* out, int clear);
 /* last sub-step of env i: contact points found / solved, joint-limit candidates / solved */
 void oracle_last_counts(const oracle_env* e, int i, int out[4]);
 /* Philox4x32-10 (for RNG parity tests) */

@@ -7,7 +7,7 @@ import os
 # first copy loaded wins; torch's bundled HIP runtime has to be that copy or device init fails.
 import torch  # noqa: F401
 
-from .config import SoloConfig, EnvState, InfoSoA
+from .config import SoloConfig, EnvState, InfoSoA, ABI_VERSION
 
 _LIB = None
 LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libsolorl_hip.so")   # SOLORL_LIB: dev A/B builds
@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/solorl.h declares
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
            "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state", "solorl_get_property",
-           "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_ppo_clip_adam", "solorl_last_error", "solorl_version")
+           "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_ppo_clip_adam", "solorl_last_error", "solorl_version",
+           "solorl_abi_version")
 
 
 class PolicyParams(C.Structure):            # solorl_policy_params
@@ -80,6 +81,10 @@ def lib():
         L.solorl_ppo_clip_adam.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoGrads), C.POINTER(AdamState), C.c_int, C.c_void_p]
         for s in SYMBOLS:
             getattr(L, s)
+        # the ctypes mirrors in config.py / this file are written against one layout of include/solorl.h's structs
+        if L.solorl_abi_version() != ABI_VERSION:
+            raise SoloRLError("%s was built for ABI version %d, this binding is written for %d: rebuild (`python -m solorl_amd.build`)"
+                              % (LIB_PATH, L.solorl_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 

@@ -51,25 +51,41 @@ def needs_build():
     return bool(os.environ.get("SOLORL_BUILD_DEFINES", "").split() or os.environ.get("SOLORL_BUILD_FLAGS", "").split())
 
 
+# solorl_hip.hip is compiled as five objects in parallel (its SOLO_TU_PART switch: one step-kernel instantiation per part 0..3 =
+# 2 * f64 + solo12, part 4 = the C ABI), ~2 min each instead of ~6 min in one piece; a -DSOLO_WAVE_TIMING dev build keeps ONE
+# translation unit (its device-side counters are a single global array).
+def _jobs(flags):
+    single = any(f.startswith("-DSOLO_WAVE_TIMING") for f in flags)
+    jobs = []
+    for name, deps in UNITS.items():
+        if name == "solorl_hip.hip" and not single:
+            for part in range(5):
+                jobs.append((os.path.join(OBJ, "solorl_hip.part%d.o" % part), deps, ["-DSOLO_TU_PART=%d" % part]))
+        else:
+            jobs.append((os.path.join(OBJ, name.replace(".hip", ".o")), deps, []))
+    return jobs
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = _flags()
-    tag = TAG
     same = _same_flags()
-    objs = []
-    for name, deps in UNITS.items():
-        o = os.path.join(OBJ, name.replace(".hip", ".o"))
+    objs, running = [], []
+    for o, deps, extra in _jobs(flags):
+        objs.append(o)
         if force or not same or _stale(o, deps):
-            cmd = [hipcc] + flags + ["-c", "-o", o, deps[0]]
+            cmd = [hipcc] + flags + extra + ["-c", "-o", o, deps[0]]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-        objs.append(o)
-    open(tag, "w").write(" ".join(flags))
+                print(" ".join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in running if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    open(TAG, "w").write(" ".join(flags))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -13,6 +13,8 @@ ROBOT_SOLO8, ROBOT_SOLO12 = 0, 1
 TASK_STAND, TASK_WALK, TASK_POINTGOAL = 0, 1, 2
 CONTROL_TORQUE, CONTROL_PD = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
+FRICTION_PYRAMID, FRICTION_CONE = 0, 1
+ABI_VERSION = 4            # SOLORL_ABI_VERSION (include/solorl.h)
 
 TASKS = {"stand": TASK_STAND, "walk": TASK_WALK, "pointgoal": TASK_POINTGOAL}
 CONTROLS = {"torque": CONTROL_TORQUE, "pd": CONTROL_PD, "fpd": CONTROL_PD, "fixed_pd": CONTROL_PD}
@@ -27,13 +29,13 @@ class SoloConfig(C.Structure):
         ("episode_length", C.c_int32), ("num_history_stack", C.c_int32), ("hold_torque", C.c_int32),
         ("use_urdf_inertia", C.c_int32), ("solver_iterations", C.c_int32), ("settle_min", C.c_int32),
         ("settle_max", C.c_int32), ("disable_termination", C.c_int32), ("precision", C.c_int32),
-        ("use_treadmill", C.c_int32),
+        ("use_treadmill", C.c_int32), ("friction_model", C.c_int32),
         ("kp", C.c_double), ("kd", C.c_double), ("max_torque", C.c_double), ("sim_dt", C.c_double),
         ("reward_dt", C.c_double), ("gravity", C.c_double), ("erp", C.c_double),
         ("linear_slop", C.c_double), ("warmstart", C.c_double), ("damping", C.c_double),
         ("max_velocity", C.c_double), ("joint_limit", C.c_double), ("goal_radius", C.c_double),
         ("treadmill_offset", C.c_double), ("treadmill_half_width", C.c_double), ("treadmill_friction", C.c_double),
-        ("solver_residual_threshold", C.c_double),
+        ("solver_residual_threshold", C.c_double), ("contact_erp", C.c_double),
     ]
 
     @property
@@ -93,6 +95,8 @@ def default_config(robot=ROBOT_SOLO12, task=TASK_WALK):
     c.max_velocity, c.joint_limit, c.goal_radius = 100.0, 10.0, 2.0
     c.use_treadmill, c.treadmill_offset, c.treadmill_half_width, c.treadmill_friction = 0, 0.49, 0.5, 0.5
     c.solver_residual_threshold = 1e-7      # K7: PyBullet's solverResidualThreshold, see include/solorl.h
+    # [K] ledger: Bullet's implicit friction cone and PyBullet's contact ERP (m_erp2 = 0.08); rounds 1-3: pyramid, 0.2
+    c.friction_model, c.contact_erp = FRICTION_CONE, 0.08
     return c
 
 
@@ -144,7 +148,10 @@ def config_from_dict(d, **overrides):
         c.kp, c.kd = float(gains[0]), float(gains[1])
     for k in ("hold_torque", "use_urdf_inertia", "solver_iterations", "disable_termination", "settle_min",
               "settle_max", "precision", "warmstart", "erp", "damping", "reward_dt", "goal_radius", "treadmill_offset",
-              "treadmill_half_width", "treadmill_friction", "solver_residual_threshold"):
+              "treadmill_half_width", "treadmill_friction", "solver_residual_threshold", "contact_erp", "friction_model"):
         if k in d:
-            setattr(c, k, type(getattr(c, k))(d[k]))
+            v = d[k]
+            if k == "friction_model" and isinstance(v, str):
+                v = {"pyramid": FRICTION_PYRAMID, "cone": FRICTION_CONE}[v]
+            setattr(c, k, type(getattr(c, k))(v))
     return c

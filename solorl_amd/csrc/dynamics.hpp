@@ -99,10 +99,20 @@ constexpr bool base_points_are_sign_patterns(const solorl_model_data& md) {
 template <typename T> struct PhysParams {
   T dt, gravity, erp, slop, warm, damping, vmax, qlim, inv_dt;
   int iterations;
-  int tm_on; T tm_hw, tm_mu;   // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
-  int pgs_pipe;                // team-mode sweep: software-pipelined (a wavefront per SIMD) or plain (two per SIMD), see pgs_team_variant
-  int urdf_inertia;            // K2: 0 = Bullet's default box inertia from the collision AABB, 1 = the URDF tensor (use_urdf_inertia)
+  T tm_hw, tm_mu;              // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
   T resid_thr;                 // sqrt(solver_residual_threshold): velocity-level change below which a solve stops (K7); < 0: never
+  T cerp;                      // error reduction of the contact rows (solorl_config contact_erp = Bullet's m_erp2); erp above: joint-limit rows (m_erp)
+  // the switches share one word (the struct travels to every non-inlined phase function in argument VGPRs: four separate ints cost the
+  // collision front its last free registers)
+  int mode;
+  enum { M_PIPE = 1, M_URDF = 2, M_CONE = 4, M_TREADMILL = 8 };
+  SD bool pgs_pipe() const { return mode & M_PIPE; }          // team-mode sweep: software-pipelined (a wavefront per SIMD) or plain (two per SIMD), see pgs_team_variant
+  SD bool urdf_inertia() const { return mode & M_URDF; }      // K2: Bullet's default box inertia from the collision AABB, or the URDF tensor (use_urdf_inertia)
+  SD bool cone() const { return mode & M_CONE; }              // solorl_config friction_model: Bullet's implicit friction cone (the two friction rows of a contact solved together)
+  SD bool tm_on() const { return mode & M_TREADMILL; }        // treadmill strip present
+  void set_mode(bool pipe, bool urdf, bool cone_, bool treadmill) {      // (host side: make_phys)
+    mode = (pipe ? M_PIPE : 0) | (urdf ? M_URDF : 0) | (cone_ ? M_CONE : 0) | (treadmill ? M_TREADMILL : 0);
+  }
 };
 // bit 24+f of a sub-step's returned mask: foot f's contact lies on the treadmill strip (foot primitive = 13 + 2f)
 SD int strip_feet_bits(int smask) {
@@ -129,10 +139,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char solo_smem_sym[];
 // it from that constant.  (Through the `extern __shared__` symbol a NON-kernel function finds the start of the dynamic LDS with a
 // scalar load from a per-kernel table -- an exposed scalar-cache round trip at the top of every phase call, and, since scalar loads
 // return out of order, an s_waitcnt lgkmcnt(0) that drains every LDS read in flight wherever the compiler re-loads it.)
-// Checked where it can be: step_team / step_lane compare the symbol's offset with the constant on entry, and
-// tests/test_abi.py reads the kernels' static LDS size from the code object.
+// Checked on the HOST: solorl_step compares the loaded kernel's static LDS size (hipFuncGetAttributes) with the constant before its
+// first launch (check_lds_base, solorl_hip.hip: SOLORL_ERR_HIP instead of wrong physics), and tests/test_abi.py reads the same
+// number from the built code object.  Nothing is checked on the device.
 #if defined(SOLO_WAVE_TIMING)
-constexpr unsigned SOLO_LDS_BASE = 80;                   // behind solo_pt_acc[10]
+constexpr unsigned SOLO_LDS_BASE = 80;                   // behind solo_pt_acc[10] -- which only the TEAM kernel references: the timing build
+                                                         // is team-mode only (check_lds_base rejects the lane-mode kernel there, by design)
 #else
 constexpr unsigned SOLO_LDS_BASE = 0;
 #endif
@@ -140,7 +152,6 @@ typedef __attribute__((address_space(3))) unsigned char solo_lds_byte;
 // (written as a non-zero LDS address minus its distance from the base: LDS offset 0 itself would be taken for the null pointer,
 // whose generic counterpart is not LDS offset 0)
 #define solo_smem (((unsigned char*)reinterpret_cast<solo_lds_byte*>(SOLO_LDS_BASE + 4096u)) - 4096)
-SD bool solo_lds_base_ok() { return (unsigned)(size_t)(solo_lds_byte*)solo_smem_sym == SOLO_LDS_BASE; }
 #endif
 #ifdef SOLO_HOST_SHIM
 template <typename T> constexpr int default_lanes() { return 1; }
@@ -436,7 +447,7 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
     dist[p] = st.pos.z + R0.c0.z * T(PR.center[0]) + R0.c1.z * T(PR.center[1]) + R0.c2.z * T(PR.center[2]);
     if (dist[p] < T(PR.margin)) mask |= 1 << p;
-    if (pp.tm_on && fabs(ty + R0.c0.y * T(PR.center[0]) + R0.c1.y * T(PR.center[1]) + R0.c2.y * T(PR.center[2])) <= pp.tm_hw) smask |= 1 << p;
+    if (pp.tm_on() && fabs(ty + R0.c0.y * T(PR.center[0]) + R0.c1.y * T(PR.center[1]) + R0.c2.y * T(PR.center[2])) <= pp.tm_hw) smask |= 1 << p;
   });
   static_for<4>([&](auto lc) {
     constexpr int L = decltype(lc)::value;
@@ -447,14 +458,14 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
       constexpr double ms_ = RB::MD.prims[20 + L].margin;
       dist[20 + L] = st.pos.z + shP.z;
       if (dist[20 + L] < T(ms_)) mask |= 1 << (20 + L);
-      if (pp.tm_on && fabs(ty + shP.y) <= pp.tm_hw) smask |= 1 << (20 + L);
+      if (pp.tm_on() && fabs(ty + shP.y) <= pp.tm_hw) smask |= 1 << (20 + L);
     } else dist[20 + L] = T(1);
     dist[12 + 2 * L] = st.pos.z + kneeP.z; dist[13 + 2 * L] = st.pos.z + footP.z;
     constexpr double mk_ = RB::MD.prims[12 + 2 * L].margin, mf_ = RB::MD.prims[13 + 2 * L].margin;   // (constexpr: no run-time model loads)
     if (dist[12 + 2 * L] < T(mk_)) mask |= 1 << (12 + 2 * L);
     if (dist[13 + 2 * L] < T(mf_)) mask |= 1 << (13 + 2 * L);
-    if (pp.tm_on && fabs(ty + kneeP.y) <= pp.tm_hw) smask |= 1 << (12 + 2 * L);
-    if (pp.tm_on && fabs(ty + footP.y) <= pp.tm_hw) smask |= 1 << (13 + 2 * L);
+    if (pp.tm_on() && fabs(ty + kneeP.y) <= pp.tm_hw) smask |= 1 << (12 + 2 * L);
+    if (pp.tm_on() && fabs(ty + footP.y) <= pp.tm_hw) smask |= 1 << (13 + 2 * L);
   });
 #pragma unroll
   for (int p = 0; p < NPRIM; p++) C.dist[p] = dist[p];
@@ -926,7 +937,7 @@ SD void finish_row(const T (&c)[ROW_CORE], int meta, const Sym6<T>& Lam, const S
   else {
     const T pen = c[12];
     T pos = T(0), vel = -rel;
-    if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * pp.erp * pp.inv_dt;
+    if (pen > T(0)) vel -= pen * pp.inv_dt; else pos = -pen * (dir == 3 ? pp.erp : pp.cerp) * pp.inv_dt;   // joint limit: m_erp, contact: m_erp2
     rhs = (pos + vel) * dinv;
   }
 }
@@ -974,7 +985,11 @@ SNI void phase_base(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned n
 // impulse, friction coefficient and leg id are fetched while row r is computed; a friction row's
 // parent is found arithmetically (parent = nlim + (r - nlim - nc)/2), so there is no dependent
 // LDS chain.  Accumulators: base delta-velocity w in registers, leg delta-rates y in LDS.
-template <typename T, int ROBOT, typename LDS, typename CH>
+// CONE (solorl_config friction_model = cone): the two friction rows of a contact -- consecutive rows rfric + 2p, rfric + 2p + 1 -- are
+// solved together as Bullet's resolveConeFrictionConstraintRows does [K]: the first row of a pair only computes its unclamped sum and
+// parks what its update needs (Pend), the second computes its own against the SAME accumulators, the pair is projected radially onto
+// the disc of radius mu * normal impulse, both deltas are applied, and the K7 residual entry is the sum of the two velocity changes.
+template <typename T, int ROBOT, typename LDS, typename CH, bool CONE = false>
 SNI void phase_pgs(CH ch, int iterations, T resid_thr, const LDS lds) {
   SubCtx<T, ROBOT>& C = ch.get();
   using R_ = LDS;
@@ -996,6 +1011,10 @@ SNI void phase_pgs(CH ch, int iterations, T resid_thr, const LDS lds) {
   // r is computed; if r+1 works on the same leg (or has row r as friction parent) the freshly
   // computed register values are forwarded instead of waiting for an LDS store->load round trip.
   struct Row { T c[ROW_CORE]; T mu, lam, lamp, y0, y1, y2; int yoff, par; };
+  struct Pend { T W[9], dinv, lam, sum; int row; } pend;      // CONE: the first friction row of a pair, waiting for the second
+  pend.dinv = T(1); pend.lam = T(0); pend.sum = T(0); pend.row = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) pend.W[k] = T(0);
   bool conv = false, viol = false;
   auto fetch = [&](int rr, Row& R) {
     const Chunk* p = corev + __mul24(rr, NCH * LN);
@@ -1022,15 +1041,40 @@ SNI void phase_pgs(CH ch, int iterations, T resid_thr, const LDS lds) {
     const T hi = fr ? R.mu * R.lamp : T(1e30);
     const T lo = fr ? -hi : T(0);
     T sum = R.lam + (R.c[18] - jdv * R.c[19]);
-    sum = sum < lo ? lo : (sum > hi ? hi : sum);
-    sum = (live && !conv) ? sum : R.lam;                  // (a converged lane's solve is over: its rows stay as they are)
-    const T delta = sum - R.lam;
-    const T dvel = fabs(delta) / R.c[19];                  // K7 residual: |delta impulse| / jacDiagABInv
-    viol = viol || (dvel > resid_thr);
-    w.a.x += R.c[9] * delta; w.a.y += R.c[10] * delta; w.a.z += R.c[11] * delta;
-    w.l.x += R.c[12] * delta; w.l.y += R.c[13] * delta; w.l.z += R.c[14] * delta;
-    const T y0 = R.y0 + R.c[15] * delta, y1 = R.y1 + R.c[16] * delta, y2 = R.y2 + R.c[17] * delta;
     const int rw = live ? r : last;
+    T delta, y0, y1, y2;
+    const bool active = live && !conv;                    // (a converged lane's solve is over: its rows stay as they are)
+    bool paired = false;
+    if constexpr (CONE) paired = fr && active;
+    if (paired) {
+      if (((r - rfric) & 1) == 0) {                        // first row of the pair: nothing is applied yet
+        pend.sum = sum; pend.lam = R.lam; pend.dinv = R.c[19]; pend.row = rw;
+#pragma unroll
+        for (int k = 0; k < 9; k++) pend.W[k] = R.c[9 + k];
+        sum = R.lam; delta = T(0);
+        y0 = R.y0; y1 = R.y1; y2 = R.y2;
+      } else {
+        T sa = pend.sum, sb = sum;
+        const T s2 = sa * sa + sb * sb;
+        if (s2 >= hi * hi) { const T sc = hi * rsqrt_fast(s2 > T(1e-30) ? s2 : T(1e-30)); sa *= sc; sb *= sc; }
+        const T da = sa - pend.lam;
+        sum = sb; delta = sb - R.lam;
+        viol = viol || (fabs(da / pend.dinv + delta / R.c[19]) > resid_thr);      // K7: the pair's entry is the SUM of the two velocity changes
+        w.a.x += pend.W[0] * da + R.c[9] * delta; w.a.y += pend.W[1] * da + R.c[10] * delta; w.a.z += pend.W[2] * da + R.c[11] * delta;
+        w.l.x += pend.W[3] * da + R.c[12] * delta; w.l.y += pend.W[4] * da + R.c[13] * delta; w.l.z += pend.W[5] * da + R.c[14] * delta;
+        y0 = R.y0 + pend.W[6] * da + R.c[15] * delta; y1 = R.y1 + pend.W[7] * da + R.c[16] * delta; y2 = R.y2 + pend.W[8] * da + R.c[17] * delta;
+        auxv[__mul24(pend.row, 4 * LN) + R_::A_LAM * LN] = sa;
+      }
+    } else {
+      sum = sum < lo ? lo : (sum > hi ? hi : sum);
+      sum = active ? sum : R.lam;
+      delta = sum - R.lam;
+      const T dvel = fabs(delta) / R.c[19];                  // K7 residual: |delta impulse| / jacDiagABInv
+      viol = viol || (dvel > resid_thr);
+      w.a.x += R.c[9] * delta; w.a.y += R.c[10] * delta; w.a.z += R.c[11] * delta;
+      w.l.x += R.c[12] * delta; w.l.y += R.c[13] * delta; w.l.z += R.c[14] * delta;
+      y0 = R.y0 + R.c[15] * delta; y1 = R.y1 + R.c[16] * delta; y2 = R.y2 + R.c[17] * delta;
+    }
     auxv[__mul24(rw, 4 * LN) + R_::A_LAM * LN] = sum;    // (dead lanes rewrite their last row's own value)
     yl[R.yoff] = y0; yl[R.yoff + LN] = y1; yl[R.yoff + 2 * LN] = y2;
     // forward what the prefetch could not have seen yet
@@ -1224,7 +1268,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     C.dist[12 + 2 * L] = dk; C.dist[13 + 2 * L] = df;
     if (dk < PRIMC(0, margin)) bits |= 1 << (12 + 2 * L);
     if (df < PRIMC(1, margin)) bits |= 1 << (13 + 2 * L);
-    if (pp.tm_on) {
+    if (pp.tm_on()) {
       if (fabs(ty + kneeP.y) <= pp.tm_hw) sbits |= 1 << (12 + 2 * L);
       if (fabs(ty + footP.y) <= pp.tm_hw) sbits |= 1 << (13 + 2 * L);
     }
@@ -1233,7 +1277,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
       const T ds = pz + shP.z;
       C.dist[20 + L] = ds;
       if (ds < SHC(margin)) bits |= 1 << (20 + L);
-      if (pp.tm_on && fabs(ty + shP.y) <= pp.tm_hw) sbits |= 1 << (20 + L);
+      if (pp.tm_on() && fabs(ty + shP.y) <= pp.tm_hw) sbits |= 1 << (20 + L);
     } else C.dist[20 + L] = T(1);              // (no such primitive: never in contact, never ranked)
 #undef SHC
 #undef PRIMC
@@ -1255,7 +1299,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     bdist = pz + bP.z;
     C.dist[p] = bdist;
     if (bdist < mg) bits |= 1 << p;
-    if (pp.tm_on && fabs(ty + bP.y) <= pp.tm_hw) { sbits |= 1 << p; bfric *= pp.tm_mu; }
+    if (pp.tm_on() && fabs(ty + bP.y) <= pp.tm_hw) { sbits |= 1 << p; bfric *= pp.tm_mu; }
   }
   if (valid && t < NQ) {    // joint limits: bit 2j = lower window, 2j+1 = upper window (same order as the row slots)
     const T q = st.q[t];
@@ -1287,7 +1331,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     }
     lbits = team_or16(sel);
   }
-  if (pp.tm_on) sbits = team_or16(sbits);     // (uniform branch)
+  if (pp.tm_on()) sbits = team_or16(sbits);     // (uniform branch)
   const int capc = contact_cap(__builtin_popcount(lbits));   // limit rows 3 and 4 take the place of contact points (see MAX_LIMITS)
   if (__builtin_popcount(mask) > capc) {
     // more primitives touch than there are contact slots (a robot lying on the ground -- the heaviest wavefronts, which set the launch
@@ -1469,7 +1513,9 @@ SNI_SCALAR void phase_finish_team(const PhysParams<T> pp, const LDS lds, int t) 
     o[E_RHS] = rhs * isB;               // finish_row's rhs already carries 1/diag
     o[E_LEG] = T(leg);
     lds.store_core(r, o);
-    lds.A(r, LDS::A_LAM) = pp.resid_thr * sJ;      // K7 in the row's units: |delta lambda~| / sJ = |delta impulse| / jacDiagABInv
+    // K7 in the row's units: |delta lambda~| / sJ = |delta impulse| / jacDiagABInv.  Friction rows of the cone model store the reciprocal
+    // instead: the pair's residual entry is the SUM of its two velocity changes, |d0 / (thr sJ0) + d1 / (thr sJ1)| > 1 (pgs_team_variant)
+    lds.A(r, LDS::A_LAM) = (fr && pp.cone()) ? rcp_fast(pp.resid_thr * sJ) : pp.resid_thr * sJ;
     lam[TRW::pos_of(r, nlt, nc) * 4] = c[13];      // warm-start impulse (0 for friction / limit rows)
   };
   emit(t, c0, meta0, mu0);
@@ -1522,7 +1568,11 @@ template <typename T> SD T team_red8(T x) {      // sum over the 8 lanes of a ha
 #ifndef SOLO_SETUP_GROUP_F64
 #define SOLO_SETUP_GROUP_F64 1
 #endif
-template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT, bool PIPE = true>
+// CONE (solorl_config friction_model = cone): Bullet's implicit friction cone [K].  A friction slot already holds the two directions of
+//   one contact, one per half; both halves take their unclamped sums against the pre-update accumulators (no Gauss-Seidel coupling c'
+//   between the two), exchange them, and scale the pair by min(1, mu lambda_n / |pair|) -- resolveConeFrictionConstraintRows' atan2 / sin /
+//   cos is this radial projection.  Its K7 residual entry is the SUM of the two velocity changes.
+template <typename T, typename LDS, int LIM, int NNS, int NFS, bool EXIT, bool PIPE = true, bool CONE = false>
 SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   // (the residual threshold of K7 reaches the sweep through the rows: phase_finish_team stores it per row, in the row's units)
   using TRW = TeamRows<T, LDS>;
@@ -1567,7 +1617,8 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
   auto fm = [](auto a, auto b, auto c) { return __builtin_elementwise_fma(a, b, c); };
   T J0[n], J1[n], J2[n], B2[n], X2[n], rh[n], cp[n], lm[n], eo[n], ex[n];
   P2 B01[n], X01[n];
-  T th[EXIT ? n : 1];                            // (K7) |delta| above which a row keeps its team iterating
+  T th[EXIT ? n : 1];                            // (K7) |delta| above which a row keeps its team iterating (cone friction rows: its reciprocal)
+  T thx[(EXIT && CONE && NFS > 0) ? NFS : 1];    // (K7, cone) the partner row's reciprocal threshold
   T lmo[NNS > 0 ? NNS : 1];                      // the partner half's impulse of the normal slots (friction bounds)
   P2 a01 = {T(0), T(0)}; T a2 = T(0);
   // Set-up in two passes.  Pass 1 issues EVERY LDS read of every slot -- unconditionally, from a safe row where the team has none, so that
@@ -1630,8 +1681,14 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       // null row's delta is 0, never above it)
       // coupling of the slot's two rows, c' = J'_{2k+1} . B~_{2k}: half 1 reduces it from its own J' and the
       // partner's B~; half 0 takes 0 (its row does not wait for anybody)
-      const T c = team_red8(J0[i] * X01[i].x + J1[i] * X01[i].y + J2[i] * X2[i]);
-      cp[i] = half ? c : T(0);
+      if constexpr (CONE && fr) {             // the cone solves a contact's two directions side by side: no coupling between them
+        cp[i] = T(0);
+        (void)thx;
+        if constexpr (EXIT) { if (r_own < 0) th[i] = T(0); thx[i - LIM - NNS] = half_swap(th[i]); }      // (a null row: the safe row's value is not a reciprocal)
+      } else {
+        const T c = team_red8(J0[i] * X01[i].x + J1[i] * X01[i].y + J2[i] * X2[i]);
+        cp[i] = half ? c : T(0);
+      }
       if constexpr (i >= LIM && i < LIM + NNS) lmo[i - LIM] = T(0);
     });
     // warm start: acc = sum over rows of B~ * lam0   (dV = M^-1 J^T lam0).  With PyBullet's default (no multibody warm start, the engine's
@@ -1713,15 +1770,36 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
       if constexpr (fric) { fr_tot++; if (!__any(hi != T(0) || lm[i] != T(0))) fr_dead++; }
 #endif
       T sp = lm[i] - d;
-      // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
-      // (cp = 0 in half 0, whose second clamp therefore repeats the first)
-      const T dfirst = clampb(sp) - lm[i];
-      sp = fm(-cp[i], half_swap(dfirst), sp);
-      const T sv = clampb(sp);
+      T sv;
+      if constexpr (CONE && fric) {
+        // both directions' unclamped sums (own: sp, partner: spx), scaled onto the disc of radius hi = lambda_n (rows are in units of mu)
+        const T spx = half_swap(sp);
+        const T s2 = fm(sp, sp, fm(spx, spx, T(1e-30)));                       // (+ 1e-30: a pair at rest scales by hi * 1e15 -> 1, not by 0 * inf)
+        T sc;
+        if constexpr (sizeof(T) == 4) {
+#ifndef SOLO_HOST_SHIM
+          // v_rsq_f32 (1 ulp: the scale only matters at the level of the sweep's other roundings); min(scale, 1) as med3(x, 0, 1), which
+          // the compiler folds into the multiply's clamp modifier (hi >= 0)
+          sc = __builtin_amdgcn_fmed3f(hi * __builtin_amdgcn_rsqf(s2), 0.0f, 1.0f);
+#else
+          sc = hi / sqrt(s2); sc = sc < T(1) ? sc : T(1);
+#endif
+        } else { sc = hi / sqrt(s2); sc = sc < T(1) ? sc : T(1); }
+        sv = sp * sc;
+      } else {
+        // position 2k (half 0) is final after the first clamp; 2k+1 (half 1) then sees its delta through c'
+        // (cp = 0 in half 0, whose second clamp therefore repeats the first)
+        const T dfirst = clampb(sp) - lm[i];
+        sp = fm(-cp[i], half_swap(dfirst), sp);
+        sv = clampb(sp);
+      }
       const T del = sv - lm[i];
-      if constexpr (EXIT) viol = viol || (fabs(del) > th[i]);
       lm[i] = sv;
       const T delx = half_swap(del);
+      if constexpr (EXIT) {
+        if constexpr (CONE && fric) viol = viol || (fabs(fm(delx, thx[i - LIM - NNS], del * th[i])) > T(1));
+        else viol = viol || (fabs(del) > th[i]);
+      }
       if constexpr (sizeof(T) != 4 && i >= LIM && i < LIM + NNS) lmo[i - LIM] += delx;
       a01 = fm(X01[i], P2{delx, delx}, fm(B01[i], P2{del, del}, a01));
       a2 = fm(X2[i], delx, fm(B2[i], del, a2));
@@ -1749,7 +1827,7 @@ SNI void pgs_team_variant(int iterations_v, const LDS lds, int t) {
 }
 
 template <typename T, int ROBOT, typename LDS>
-SD void phase_pgs_team(int iterations_, bool warm_on, bool early_exit, bool pipe, const LDS lds, int t) {
+SD void phase_pgs_team(int iterations_, bool warm_on, bool early_exit, bool pipe, bool cone, const LDS lds, int t) {
   const int iterations = (iterations_ & 0xFFFF) | (warm_on ? 1 << 30 : 0);       // (one argument register: pgs_team_variant)
   constexpr int LN = LDS::LANES;
   int nlt, nc, ncmax, anylim;
@@ -1769,12 +1847,13 @@ SD void phase_pgs_team(int iterations_, bool warm_on, bool early_exit, bool pipe
   else if (ncmax >= 3) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 #endif
-#define SOLO_SWEEP_L(N_, F_) do { if (early_exit) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, true>(iterations, lds, t); \
-                                                    else pgs_team_variant<T, LDS, 0, N_, F_, true>(iterations, lds, t); } \
-                                  else if (pipe) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false>(iterations, lds, t); \
-                                                   else pgs_team_variant<T, LDS, 0, N_, F_, false>(iterations, lds, t); } \
-                                  else { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false, false>(iterations, lds, t); \
-                                         else pgs_team_variant<T, LDS, 0, N_, F_, false, false>(iterations, lds, t); } } while (0)
+#define SOLO_SWEEP_C(N_, F_, C_) do { if (early_exit) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, true, true, C_>(iterations, lds, t); \
+                                                        else pgs_team_variant<T, LDS, 0, N_, F_, true, true, C_>(iterations, lds, t); } \
+                                      else if (pipe) { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false, true, C_>(iterations, lds, t); \
+                                                       else pgs_team_variant<T, LDS, 0, N_, F_, false, true, C_>(iterations, lds, t); } \
+                                      else { if (anylim) pgs_team_variant<T, LDS, 1, N_, F_, false, false, C_>(iterations, lds, t); \
+                                             else pgs_team_variant<T, LDS, 0, N_, F_, false, false, C_>(iterations, lds, t); } } while (0)
+#define SOLO_SWEEP_L(N_, F_) do { if (cone) SOLO_SWEEP_C(N_, F_, true); else SOLO_SWEEP_C(N_, F_, false); } while (0)
   switch (ncmax) {       // wave-uniform
     case 0:
       if (anylim) { if (early_exit) pgs_team_variant<T, LDS, 1, 0, 0, true>(iterations, lds, t); else pgs_team_variant<T, LDS, 1, 0, 0, false>(iterations, lds, t); }
@@ -1798,6 +1877,7 @@ SD void phase_pgs_team(int iterations_, bool warm_on, bool early_exit, bool pipe
     default: SOLO_SWEEP_L(4, 8); break;
   }
 #undef SOLO_SWEEP_L
+#undef SOLO_SWEEP_C
 }
 
 // apply + integrate, team mode: impulse cache and joints one per lane, base pose on the leader.
@@ -1880,7 +1960,7 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
     C.sn[t] = sn; C.cs[t] = cs;
   }
   SOLO_PT(0);
-  const bool ui = pp.urdf_inertia != 0;     // (uniform) K2: URDF tensors instead of the box rule
+  const bool ui = pp.urdf_inertia();     // (uniform) K2: URDF tensors instead of the box rule
   if (ui) phase_front_team<T, ROBOT, LDS, CH, true>(ch, pp, lds, t, valid, lead);
   else phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
 #ifdef SOLO_DUP_FRONT      // dev: run an idempotent phase twice -- the launch-time delta is that phase's true cost
@@ -1912,7 +1992,7 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
 #endif
   SOLO_PT(6);
-  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.warm != T(0), pp.resid_thr >= T(0), pp.pgs_pipe != 0, lds, t);
+  phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.warm != T(0), pp.resid_thr >= T(0), pp.pgs_pipe(), pp.cone(), lds, t);
   SOLO_PT(7);
   phase_integrate_team<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds, t, valid, lead);
   SOLO_PT(8);
@@ -1927,7 +2007,7 @@ template <typename T, int ROBOT, typename LDS>
 SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, T* lam_prev, unsigned nstride, const LDS& lds) {
   using CH = CtxPriv<T, ROBOT>;
   const CH ch{&C};
-  if (pp.urdf_inertia) {
+  if (pp.urdf_inertia()) {
     phase_detect<T, ROBOT, CH, true>(ch, pp);
     phase_leg<T, ROBOT, 0, LDS, CH, true>(ch, pp, lam_prev, nstride, lds);
     phase_leg<T, ROBOT, 1, LDS, CH, true>(ch, pp, lam_prev, nstride, lds);
@@ -1941,7 +2021,8 @@ SD int substep(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, T* lam_prev, unsigne
     phase_leg<T, ROBOT, 3, LDS, CH, false>(ch, pp, lam_prev, nstride, lds);
   }
   phase_base<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-  phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, pp.resid_thr, lds);
+  if (pp.cone()) phase_pgs<T, ROBOT, LDS, CH, true>(ch, pp.iterations, pp.resid_thr, lds);
+  else phase_pgs<T, ROBOT, LDS, CH>(ch, pp.iterations, pp.resid_thr, lds);
   phase_integrate<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   return C.mask | strip_feet_bits(C.smask);
 }

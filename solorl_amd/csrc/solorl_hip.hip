@@ -29,10 +29,20 @@
 
 using namespace solo;
 
+#ifndef SOLO_TU_PART
+#define SOLO_TU_PART -1      // translation-unit split, see dispatch_step below
+#endif
+// the thread-local error message lives in the part that holds the C ABI; the other parts (and solorl_ppo.hip) report through it
+extern "C" __attribute__((visibility("hidden"))) int solorl_fail_(int code, const char* msg);
+
 namespace {
 
+#if SOLO_TU_PART == -1 || SOLO_TU_PART == 4
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#else
+int fail(int code, const std::string& msg) { return solorl_fail_(code, msg.c_str()); }
+#endif
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SOLORL_ERR_HIP, std::string(#x ": ") + hipGetErrorString(e_)); } while (0)
 
 constexpr int DMAX = SOLORL_STATE_MAX_OBS;   // 42
@@ -1009,10 +1019,10 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   p.dt = (T)c.sim_dt; p.gravity = (T)c.gravity; p.erp = (T)c.erp; p.slop = (T)c.linear_slop; p.warm = (T)c.warmstart;
   p.damping = (T)c.damping; p.vmax = (T)c.max_velocity; p.qlim = (T)c.joint_limit; p.inv_dt = (T)(1.0 / c.sim_dt);
   p.iterations = c.solver_iterations;
-  p.tm_on = c.use_treadmill; p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
-  p.urdf_inertia = c.use_urdf_inertia ? 1 : 0;
-  p.pgs_pipe = 1;
+  p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
   p.resid_thr = c.solver_residual_threshold > 0 ? (T)sqrt(c.solver_residual_threshold) : T(-1);
+  p.cerp = (T)c.contact_erp;
+  p.set_mode(true, c.use_urdf_inertia != 0, c.friction_model == SOLORL_FRICTION_CONE, c.use_treadmill != 0);
   return p;
 }
 
@@ -1023,7 +1033,8 @@ static int check_lds_base(const void* kernel, bool& checked) {
   hipFuncAttributes a;
   HIP_TRY(hipFuncGetAttributes(&a, kernel));
   if (a.sharedSizeBytes != (size_t)SOLO_LDS_BASE)
-    return fail(SOLORL_ERR_HIP, "step kernel has static LDS: the phase functions' dynamic-LDS base constant does not hold");
+    return fail(SOLORL_ERR_HIP, "step kernel's static LDS size differs from SOLO_LDS_BASE: the phase functions' dynamic-LDS base constant does not hold "
+                                "(a -DSOLO_WAVE_TIMING build runs team mode only)");
   checked = true;
   return 0;
 }
@@ -1043,8 +1054,9 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
     // Pipelined sweep while every wavefront has a SIMD to itself, plain sweep above that (pgs_team_variant: 8192 envs 0.226 ->
     // 0.210 ms per step).  The two are re-associations of the same sums, so an env's last bits depend on which side of
     // h->simds workgroups its batch is; SOLORL_PGS_PIPE=1 (or 0) pins one variant for every batch size.
-    pp.pgs_pipe = (int)grid.x <= h->simds ? 1 : 0;
-    if (h->pipe_override >= 0) pp.pgs_pipe = h->pipe_override;
+    bool pipe = (int)grid.x <= h->simds;
+    if (h->pipe_override >= 0) pipe = h->pipe_override != 0;
+    pp.mode = (pp.mode & ~PhysParams<T>::M_PIPE) | (pipe ? PhysParams<T>::M_PIPE : 0);
     hipLaunchKernelGGL(kt, grid, block, team_smem, st, sf, si, (const T*)h->snf, (const int*)h->sni, h->M, h->L, N,
                        make_env_params(h), pp, actions, out, mode);
     HIP_TRY(hipGetLastError());
@@ -1070,12 +1082,43 @@ int launch_step(solorl_env* h, T* sf, int* si, int N, const float* actions, cons
   return 0;
 }
 
+}  // namespace
+
+// ---- translation-unit split (build time only; solorl_amd/build.py).  The step kernels' phase functions are what takes minutes to
+// compile, once per (arithmetic type, robot): this file is compiled five times in parallel -- SOLO_TU_PART = 0..3 emit ONE
+// launch_step instantiation each (part = 2 * f64 + solo12) behind a hidden C symbol, part 4 the C ABI and every other kernel --
+// or once with SOLO_TU_PART undefined (everything; the -DSOLO_WAVE_TIMING dev build, whose device-side counters must live in one
+// translation unit).  The types below the anonymous namespace are the same source in every part.
+#define SOLO_LAUNCH_ARGS solorl_env* h, void* sf, int* si, int N, const float* actions, const void* out, int mode, void* st
+extern "C" {
+__attribute__((visibility("hidden"))) int solorl_launch_part0(SOLO_LAUNCH_ARGS);
+__attribute__((visibility("hidden"))) int solorl_launch_part1(SOLO_LAUNCH_ARGS);
+__attribute__((visibility("hidden"))) int solorl_launch_part2(SOLO_LAUNCH_ARGS);
+__attribute__((visibility("hidden"))) int solorl_launch_part3(SOLO_LAUNCH_ARGS);
+}
+#define SOLO_DEFINE_PART(K_, T_, R_) \
+  extern "C" int solorl_launch_part##K_(SOLO_LAUNCH_ARGS) { \
+    return launch_step<T_, R_>(h, (T_*)sf, si, N, actions, *(const Outputs*)out, mode, (hipStream_t)st); }
+#if SOLO_TU_PART == -1 || SOLO_TU_PART == 0
+SOLO_DEFINE_PART(0, float, 0)
+#endif
+#if SOLO_TU_PART == -1 || SOLO_TU_PART == 1
+SOLO_DEFINE_PART(1, float, 1)
+#endif
+#if SOLO_TU_PART == -1 || SOLO_TU_PART == 2
+SOLO_DEFINE_PART(2, double, 0)
+#endif
+#if SOLO_TU_PART == -1 || SOLO_TU_PART == 3
+SOLO_DEFINE_PART(3, double, 1)
+#endif
+
+#if SOLO_TU_PART == -1 || SOLO_TU_PART == 4        // ---- the C ABI and everything that is not a step kernel
+namespace {
+
 int dispatch_step(solorl_env* h, void* sf, int* si, int N, const float* actions, const Outputs& out, int mode, hipStream_t st) {
   const bool s12 = h->cfg.robot == SOLORL_ROBOT_SOLO12;
-  if (!h->f64) return s12 ? launch_step<float, 1>(h, (float*)sf, si, N, actions, out, mode, st)
-                          : launch_step<float, 0>(h, (float*)sf, si, N, actions, out, mode, st);
-  return s12 ? launch_step<double, 1>(h, (double*)sf, si, N, actions, out, mode, st)
-             : launch_step<double, 0>(h, (double*)sf, si, N, actions, out, mode, st);
+  if (!h->f64) return s12 ? solorl_launch_part1(h, sf, si, N, actions, &out, mode, st) : solorl_launch_part0(h, sf, si, N, actions, &out, mode, st);
+  return s12 ? solorl_launch_part3(h, sf, si, N, actions, &out, mode, st) : solorl_launch_part2(h, sf, si, N, actions, &out, mode, st);
 }
 
 template <typename T> int build_snapshots_t(solorl_env* h) {
@@ -1116,6 +1159,8 @@ int check_cfg(const solorl_config* c) {
   if (!(c->sim_dt > 0) || !(c->goal_radius > 1.0)) return fail(SOLORL_ERR_INVALID, "sim_dt must be > 0 and goal_radius > 1");
   if (c->use_treadmill && !(c->treadmill_half_width > 0 && c->treadmill_friction >= 0)) return fail(SOLORL_ERR_INVALID, "bad treadmill parameters");
   if (!(c->solver_residual_threshold >= 0)) return fail(SOLORL_ERR_INVALID, "solver_residual_threshold must be >= 0");
+  if (c->friction_model != SOLORL_FRICTION_PYRAMID && c->friction_model != SOLORL_FRICTION_CONE) return fail(SOLORL_ERR_INVALID, "friction_model must be pyramid or cone");
+  if (!(c->contact_erp >= 0 && c->contact_erp <= 1) || !(c->erp >= 0 && c->erp <= 1)) return fail(SOLORL_ERR_INVALID, "erp / contact_erp must lie in [0, 1]");
   if (c->precision != SOLORL_PRECISION_F32 && c->precision != SOLORL_PRECISION_F64) return fail(SOLORL_ERR_INVALID, "bad precision");
   return 0;
 }
@@ -1126,7 +1171,7 @@ extern "C" {
 
 const char* solorl_last_error(void) { return g_err.c_str(); }
 // (the library's other translation units report through the same thread-local message; not part of the ABI)
-extern "C" __attribute__((visibility("hidden"))) int solorl_fail_(int code, const char* msg) { return fail(code, msg); }
+extern "C" int solorl_fail_(int code, const char* msg) { return fail(code, msg); }
 
 #ifdef SOLO_WAVE_TIMING
 extern "C" int solorl_debug_wave_times(unsigned long long* out, int nwaves, int reset) {    // [nwaves][SOLO_WT_FIELDS]
@@ -1170,7 +1215,8 @@ int solorl_ppo_loss(const float* mean, const float* logstd, const float* values,
   HIP_TRY(hipGetLastError());
   return 0;
 }
-const char* solorl_version(void) { return "solorl-hip 0.1 (gfx950)"; }
+const char* solorl_version(void) { return "solorl-hip 0.4 (gfx950)"; }
+int solorl_abi_version(void) { return SOLORL_ABI_VERSION; }
 
 int solorl_default_config(solorl_config* c, int robot, int task) {
   if (!c) return fail(SOLORL_ERR_INVALID, "null config");
@@ -1183,6 +1229,7 @@ int solorl_default_config(solorl_config* c, int robot, int task) {
   c->joint_limit = 10.0; c->goal_radius = 2.0;
   c->use_treadmill = 0; c->treadmill_offset = 0.49; c->treadmill_half_width = 0.5; c->treadmill_friction = 0.5;
   c->solver_residual_threshold = 1e-7;     // PyBullet's solverResidualThreshold (K7), see include/solorl.h
+  c->friction_model = SOLORL_FRICTION_CONE; c->contact_erp = 0.08;      // [K] ledger, DESIGN.md section 3 (rounds 1-3: pyramid, 0.2)
   return 0;
 }
 
@@ -1443,3 +1490,4 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
 }
 
 }  // extern "C"
+#endif  // SOLO_TU_PART: the C ABI part

@@ -10,23 +10,50 @@ import tempfile
 LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 
-def disassemble(lib_path):
-    with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
-        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path, os.path.join(d, "x.so")])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(lib_path, workdir):
+    """gfx950 code objects of the library: its .hip_fatbin section holds one offload bundle per translation unit (the engine is built
+    from several, solorl_amd/build.py), back to back -- split at the bundle magic, unbundle each."""
+    fat = os.path.join(workdir, "fat.bin")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path, os.path.join(workdir, "x.so")])
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    out = []
+    for k, a in enumerate(starts):
+        part = os.path.join(workdir, "fat%d.bin" % k)
+        open(part, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        co = os.path.join(workdir, "dev%d.co" % k)
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+        if os.path.getsize(co) > 0:
+            out.append(co)
+    return out
+
+
+def disassemble(lib_path):
+    """Disassembly of every code object, concatenated.  A function template instantiated in several translation units (the sweeps
+    depend on the arithmetic type only, the units are split by type AND robot) appears once per unit: later copies are renamed
+    `<name>.dupN` so that per-function statistics are never mixed (the copies are identical code)."""
+    out, seen = [], {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in _code_objects(lib_path, d):
+            for line in subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True).splitlines():
+                m = re.match(r"^([0-9a-f]+) <([^>]+)>:", line)
+                if m:
+                    k = seen.get(m.group(2), 0)
+                    seen[m.group(2)] = k + 1
+                    if k:
+                        line = "%s <%s.dup%d>:" % (m.group(1), m.group(2), k)
+                out.append(line)
+    return "\n".join(out)
 
 
 def kernel_static_lds(lib_path):
     """{kernel name: static LDS bytes (.group_segment_fixed_size of the code object's metadata)}"""
     with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
-        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path, os.path.join(d, "x.so")])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+        notes = "\n".join(subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True) for co in _code_objects(lib_path, d))
     out, size = {}, None
     for line in notes.splitlines():       # per kernel the keys come in alphabetical order: the size line precedes the name line
         m = re.search(r"\.group_segment_fixed_size:\s*(\d+)", line)
@@ -45,7 +72,7 @@ def function_stats(lib_path):
     for line in disassemble(lib_path).splitlines():
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
         if m:
-            cur = out.setdefault(m.group(1), dict(insts=0, scratch=0, flat=0, **{"global": 0}))
+            cur = out.setdefault(m.group(1), dict(insts=0, scratch=0, flat=0, **{"global": 0})) if ".dup" not in m.group(1) else None
             continue
         if cur is None or "\t" not in line:
             continue
@@ -74,7 +101,7 @@ def loop_stats(lib_path, name_filter):
     out = {}
     off_re = re.compile(r"//\s*([0-9A-Fa-f]+):")
     for name, lines in funcs.items():
-        if name_filter not in name or not lines:
+        if name_filter not in name or not lines or ".dup" in name:
             continue
         base = int(off_re.search(lines[0]).group(1), 16)
         rows = []

@@ -26,12 +26,32 @@ def init_from_env(device_type="cuda"):
     w = int(os.environ.get("WORLD_SIZE", "1"))
     if w > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        pin_rccl_from_env()
         if device_type == "cuda":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
         else:
             dist.init_process_group("gloo")
     return rank(), world()
+
+
+def pin_rccl_from_env():
+    """the 80 KB gradient bucket is latency-bound, a tree / direct exchange suits it better than a ring.  RCCL reads
+    its algorithm / protocol filters (NCCL_ALGO, NCCL_PROTO) when the communicator is created, so they have to be in the environment
+    BEFORE init_process_group: SOLORL_RCCL_ALGO / SOLORL_RCCL_PROTO (e.g. Tree / LL) are exported as those here.  Unset (the default)
+    leaves the choice to RCCL's own tuner: a filter that excludes every algorithm of some collective (broadcast only has Ring)
+    fails the run, and no box of this project has had two GPUs to try one on -- bench.py records what was in effect and
+    the measured bucket latency beside an 8-byte all-reduce, which is what says whether the tuner's choice is latency-bound."""
+    for src, dst in (("SOLORL_RCCL_ALGO", "NCCL_ALGO"), ("SOLORL_RCCL_PROTO", "NCCL_PROTO")):
+        v = os.environ.get(src)
+        if v:
+            os.environ[dst] = v
+    return rccl_env()
+
+
+def rccl_env():
+    return {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE")
+            if os.environ.get(k) is not None}
 
 
 class FlatGradBucket:

@@ -44,6 +44,55 @@ def _side_stream_warmup(fn, iters=3):
     torch.cuda.current_stream().wait_stream(s)
 
 
+def probe_captured_allreduce(dev, numel, replays=8, time_it=False):
+    """Does an all-reduce(sum) of `numel` floats -- the real bucket size -- run at every REPLAY of a captured graph?  (A collective that
+    ran at capture time only would leave stale data.)  Returns (ok, seconds per replay or None); ok is the same on every rank.
+
+    Protocol (a rank whose capture raised must not sit in a different collective than its peers): every step that can
+    differ between ranks is followed by an EAGER MIN all-reduce of a flag that every rank reaches --
+      1. eager all-reduce (communicator set up outside any capture)
+      2. capture, in a try block                       -> agree: did EVERY rank capture?  no: return False everywhere, nobody replays
+      3. `replays` replays with different inputs, each result checked against the closed form   -> agree on the outcome."""
+    import time
+    import torch.distributed as dist
+    w, r = D.world(), D.rank()
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    probe = torch.zeros(int(numel), device=dev)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize()
+    g, captured = None, True
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, **capture_kwargs()):
+            dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+    except Exception:
+        captured = False
+    if not agree(captured):
+        return False, None
+    ok = True
+    for k in range(1, replays + 1):
+        probe.fill_(float(k * (r + 1)))
+        g.replay()
+        torch.cuda.synchronize()
+        ok = ok and bool((probe == float(k * w * (w + 1) // 2)).all().item())
+    ok = agree(ok)
+    sec = None
+    if ok and time_it:
+        probe.zero_()                         # (sums of zeros: the timing loop cannot overflow)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            g.replay()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / 50
+    return ok, sec
+
+
 class GraphedRollout:
     """One graph = num_steps x (policy.act, env.step, storage.append).  Episode statistics need nothing here: the step
     kernel accumulates them on the device (include/solorl.h `ep_stats`), replayed or not."""
@@ -197,15 +246,16 @@ class GraphedPPO(PPO):
         self._stats.zero_(); self._off.zero_()
         if self._mb is not None:
             self._mb.reset()
-        # world > 1: one flat-bucket all-reduce per optimizer step, between the gradients and the clip.  With the nccl
-        # (= RCCL) backend the collective is CAPTURED with the rest, so a mini-batch step stays ONE graph replay (gradients ->
-        # ncclAllReduce(sum) -> clip + Adam with grad_scale = 1 / world in the same launch); a probe graph checks on every rank that a
-        # captured all-reduce really runs at replay, and all ranks agree on the outcome.  Otherwise (gloo rehearsal, a failed
-        # probe, SOLORL_SPLIT_ALLREDUCE=1): gradients graph -> eager all-reduce -> optimizer graph, as in round 2.
+        # world > 1: one flat-bucket all-reduce per optimizer step, between the gradients and the clip.  Default: the
+        # SPLIT form -- gradients graph -> eager all-reduce -> optimizer graph (clip + Adam with grad_scale = 1 / world in one launch).
+        # SOLORL_CAPTURE_ALLREDUCE=1 with the nccl (= RCCL) backend captures the collective with the rest, so that a mini-batch step is
+        # ONE graph replay; a probe graph of the real bucket size first checks on every rank that a captured all-reduce really runs
+        # at replay (probe_captured_allreduce).  Opt-in because it has never run on two GPUs.
         w = D.world()
         self._split = False
         if w > 1:
             self._split = not self._collective_is_capturable(dev)
+        self.allreduce_in_graph = w > 1 and not self._split
         if self._ca is not None:
             self._ca.S.grad_scale = 1.0 / w          # the bucket arrives SUMMED (all_reduce_sum); the scale is fused into the step
         reduce_ = self.bucket.all_reduce_sum if self._ca is not None else self.bucket.all_reduce_mean
@@ -227,30 +277,15 @@ class GraphedPPO(PPO):
         self._built_for = (id(storage), n, m)
 
     def _collective_is_capturable(self, dev):
-        """True on every rank or on none: the backend is nccl (RCCL), and a probe graph holding one all_reduce(sum) gives the right
-        sum at two replays with different inputs (a collective that ran at capture time only would return stale data)."""
+        """Whether the bucket all-reduce goes INSIDE the captured mini-batch step.  Opt-in (SOLORL_CAPTURE_ALLREDUCE=1) until a real
+        multi-GPU run has exercised it: no box of this project has had two GPUs, so the split form (graph -> eager all-reduce -> graph)
+        stays the default and `allreduce_in_graph` is recorded with every result."""
         import os
-        import torch.distributed as dist
-        ok = D.backend() == "nccl" and os.environ.get("SOLORL_SPLIT_ALLREDUCE", "0") == "0"
-        if ok:
-            try:
-                probe = torch.zeros(256, device=dev)
-                dist.all_reduce(probe)                                   # communicator set up outside the capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, **capture_kwargs()):
-                    dist.all_reduce(probe, op=dist.ReduceOp.SUM)
-                w, r = D.world(), D.rank()
-                for k in (1.0, 3.0):
-                    probe.fill_(k * (r + 1))
-                    g.replay()
-                    torch.cuda.synchronize()
-                    ok = ok and bool((probe == k * w * (w + 1) / 2).all().item())
-            except Exception:
-                ok = False
-        flag = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                      # (eager; every rank reaches this line)
-        return bool(flag.item())
+        want = D.backend() == "nccl" and os.environ.get("SOLORL_CAPTURE_ALLREDUCE", "0") == "1" and os.environ.get("SOLORL_SPLIT_ALLREDUCE", "0") == "0"
+        if not want:
+            return False
+        ok, _ = probe_captured_allreduce(dev, self.bucket.flat.numel())
+        return ok
 
     def update(self, storage):
         if not storage.rewards.is_cuda:

@@ -86,7 +86,7 @@ class SoloVecEnv:
     """Batched SoloBaseEnv on one MI355X.  ``config`` is a reference-style dict (configs/*.yaml)
     or a ``SoloConfig``."""
 
-    def __init__(self, config, num_envs, device=None, seed=1, env_id_offset=0, **overrides):
+    def __init__(self, config, num_envs, device=None, seed=1, env_id_offset=0, applied_torque=False, **overrides):
         self.cfg = config.copy() if isinstance(config, SoloConfig) else config_from_dict(config, **overrides)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
@@ -118,8 +118,12 @@ class SoloVecEnv:
         # finished-episode accumulators [fields][N], updated by the step kernel itself (include/solorl.h ep_stats)
         self._ep_stats = torch.zeros((EPSTAT_FIELDS, N), dtype=torch.float32, **kw)
         # the torques the step applied (include/solorl.h applied_torque): allocated on request only (record_applied_torque())
-        self._tau = None
-        self._info_c = InfoSoA(ep_stats=self._ep_stats.data_ptr(), applied_torque=None, **{k: self._info[k].data_ptr() for k in _INFO_KEYS})
+        # (constructor flag `applied_torque`, or record_applied_torque() before the first step: the pointer is a kernel argument, and a HIP
+        # graph captured earlier would keep replaying the NULL it was captured with)
+        self._tau = torch.zeros((N, self.act_dim), dtype=torch.float32, **kw) if applied_torque else None
+        self._steps_issued = 0
+        self._info_c = InfoSoA(ep_stats=self._ep_stats.data_ptr(), applied_torque=None if self._tau is None else self._tau.data_ptr(),
+                               **{k: self._info[k].data_ptr() for k in _INFO_KEYS})
         self.ob_rms = None          # VecNormalize(ob=False): agents/ppo/envs.py:26, read at train.py:126
         self.closed = False
 
@@ -147,6 +151,7 @@ class SoloVecEnv:
         if actions.shape != (self.nenvs, self.act_dim):
             raise AssertionError("actions must be [%d, %d]" % (self.nenvs, self.act_dim))   # solo.py:226
         a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._steps_issued += 1
         with torch.cuda.device(self.device):
             _native.check(self.L.solorl_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
                                              C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
@@ -174,6 +179,7 @@ class SoloVecEnv:
         d = self._done if done_out is None else done_out
         if not (d.is_cuda and d.device == self.device and d.dtype == torch.uint8 and d.is_contiguous() and tuple(d.shape) == (self.nenvs,)):
             raise AssertionError("done_out must be a contiguous uint8 [%d] tensor on %s" % (self.nenvs, self.device))
+        self._steps_issued += 1
         with torch.cuda.device(self.device):
             _native.check(self.L.solorl_step(self._h, a, po, pr, C.c_void_p(d.data_ptr()), C.byref(self._info_c), self._stream()))
         return o, r, d, self._info
@@ -205,9 +211,14 @@ class SoloVecEnv:
         return out
 
     def record_applied_torque(self):
-        """From now on every step also writes the joint torques it applied (after the clip / PD law, solo.py:224-259) into the
-        returned [N, A] tensor (overwritten by the next step)."""
+        """Every step also writes the joint torques it applied (after the clip / PD law, solo.py:224-259) into the returned [N, A]
+        tensor (overwritten by the next step).  Must be enabled before the first step (or with the constructor's
+        ``applied_torque=True``): the destination is a kernel argument, so a rollout or bench graph captured earlier would keep
+        replaying without it -- enabling it late raises instead of being silently ignored by those graphs."""
         if self._tau is None:
+            if self._steps_issued:
+                raise _native.SoloRLError("record_applied_torque() after %d steps: step launches (and any HIP graph captured from them) already "
+                                          "carry a NULL applied_torque pointer; construct the env with applied_torque=True" % self._steps_issued)
             self._tau = torch.zeros((self.nenvs, self.act_dim), dtype=torch.float32, device=self.device)
             self._info_c.applied_torque = self._tau.data_ptr()
         return self._tau

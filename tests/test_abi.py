@@ -34,7 +34,7 @@ def test_default_config_matches_python_mirror(lib):
             c = SoloConfig()
             assert lib.solorl_default_config(C.byref(c), robot, task) == 0
             assert bytes(c) == bytes(default_config(robot, task))
-    assert C.sizeof(SoloConfig) == 14 * 4 + 17 * 8
+    assert C.sizeof(SoloConfig) == 16 * 4 + 18 * 8        # 15 int32 (+ 4 bytes of padding before the doubles) + 18 doubles
     assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 24 + 2 * 42 + 2 + 4 + 5 + 1) + 4 * 4
 
 
@@ -135,11 +135,13 @@ def test_team_mode_phases_do_not_spill_or_use_flat(lib):
     # is register-only -- no scratch, no LDS read, no global or FLAT access (its only LDS writes are the cold block that
     # publishes a team's result when its residual falls below the K7 threshold) -- at 26 VALU instructions per slot
     sweeps = devcode.loop_stats(build.LIB, "pgs_team_variantIfNS")
-    assert len(sweeps) == 50               # 17 slot sets x {pipelined (default), K7 residual exit} + 16 plain ones (SOLORL_PGS_PIPE=0)
+    # 17 slot sets x {pipelined, K7 residual exit} + 16 plain ones (SOLORL_PGS_PIPE=0) with the friction pyramid, and the 16 slot sets
+    # that have contacts x the same three with the friction cone (3 more VALU instructions per friction slot)
+    assert len(sweeps) == 50 + 48
     for n, s in sweeps.items():
-        m = re.search(r"Li(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)EEE", n)
-        lim, nn, nf, early, pipe = (int(x) for x in m.groups())
-        nslots = lim + nn + nf
+        m = re.search(r"Li(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)EEE", n)
+        lim, nn, nf, early, pipe, cone = (int(x) for x in m.groups())
+        nslots = lim + nn + nf + (3 * nf * cone) / 27.0
         if nn + nf == 0:
             continue                       # (the limit-only sweep is 1 slot)
         assert s["loop"][0] is not None, n
