@@ -121,6 +121,10 @@ typedef struct solorl_config {
    * m_erp, which the joint-limit rows use.  PyBullet's physics server sets m_erp2 = 0.08 beside m_erp = 0.2 [K]; rounds 1-3 used one
    * value (0.2) for both.  DESIGN.md section 3 ([K] ledger) has the measured difference. */
   double contact_erp;
+  /* Collision margin around every collision shape [m].  Bullet gives the convex hulls of a URDF import a 1 mm margin (gUrdfDefaultCollisionMargin,
+   * SURVEY.md Appendix B K6 [K]): the effective shape is the hull swept by a sphere of that radius, so every support point lies the
+   * margin further down.  The analytic primitives were fitted to the bare meshes (tools/compile_model.py); rounds 1-3 ran them bare (0). */
+  double collision_margin;
 } solorl_config;
 
 /* Struct-of-arrays info block (replaces the per-env dicts of baseEnv.py:62-66).  Every pointer is

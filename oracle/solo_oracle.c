@@ -29,7 +29,7 @@
  * lets a test impose those numbers here to measure what they cost (tests/test_oracle_caps.py) -- the parity tests run uncapped. */
 #define NPT_MAX (4 * NL_MAX)                       /* contact points: <= 4 per link in the manifold model, NP_MAX primitives otherwise */
 #define MAX_ROWS (2 * SOLORL_MAX_DOF + 3 * NPT_MAX)
-#define HULL_MARGIN 0.001 /* collision margin of URDF-imported convex hulls; oracle_set_option("hull_margin") */
+/* collision margin of URDF-imported convex hulls: solorl_config collision_margin, both contact models */
 #define ITER_HIST 128
 /* A joint-limit row exists while the joint is AT or BEYOND its limit (margin <= 0): btMultiBodyJointLimitConstraint::createConstraintRows
  * skips a row whose `penetration > 0` [K5].  (Rounds 1-2: a speculative row from 0.5 rad before the limit; ORACLE_LIMIT_WINDOW=0.5
@@ -135,9 +135,7 @@ struct oracle_env {
   int opt_gyro;                  /* 1 (default): gyroscopic term w x I w (btMultiBody::m_useGyroTerm) */
   int opt_limit_split;           /* 1: a joint more than 0.04 rad beyond its limit loses the positional term (btMultiBodyJointLimitConstraint with
                                   * m_splitImpulse on and no split-impulse pass for multibodies) and uses erp2 */
-  double opt_prim_margin;        /* collision margin added around the primitives (Bullet: 1 mm around URDF hulls; the primitives carry none) */
   double opt_break_scale;        /* scale of every contact-breaking threshold (gContactBreakingThreshold 0.02) */
-  double opt_hull_margin;        /* manifold model: the hulls' collision margin (HULL_MARGIN) */
   int64_t (*iter_hist)[ITER_HIST]; /* [N][ITER_HIST]: sub-steps that had rows, by the number of PGS sweeps they ran */
 };
 typedef struct manifold_t { int n; double local[4][3], worldB[4][3], dist[4], lam[4]; } manifold_t;
@@ -312,7 +310,7 @@ static int collide_primitives(const oracle_env* E, const solorl_env_state* s, co
     double P[3];
     if ((skip_links >> prim_of(E, p)->link) & 1u) continue;
     /* a collision margin m around a shape (its Minkowski sum with a sphere) lowers the support point towards the plane by m */
-    const double d = prim_point(E, K, p, P) - E->opt_prim_margin;
+    const double d = prim_point(E, K, p, P) - E->cfg.collision_margin;
     P[2] = d;
     if (d < prim_of(E, p)->margin * E->opt_break_scale) {
       cpoint_t* c = &cp[n++];
@@ -340,7 +338,7 @@ static int collide_manifolds(oracle_env* E, int ei, const kin_t* K, cpoint_t* cp
     if (!have) {   /* links without a primitive (lower legs): threshold from the hull's own bounding sphere about the COM */
       double lo[3] = {1e9, 1e9, 1e9}, hi[3] = {-1e9, -1e9, -1e9}, c[3], hx[3];
       for (int i = 0; i < H->n; i++) for (int k = 0; k < 3; k++) { if (H->v[i][k] < lo[k]) lo[k] = H->v[i][k]; if (H->v[i][k] > hi[k]) hi[k] = H->v[i][k]; }
-      for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]) - E->md->links[l].com[k]; hx[k] = 0.5 * (hi[k] - lo[k]) + E->opt_hull_margin; }
+      for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]) - E->md->links[l].com[k]; hx[k] = 0.5 * (hi[k] - lo[k]) + E->cfg.collision_margin; }
       thr = 0.02 * (v3norm(c) + v3norm(hx)) * E->opt_break_scale; fric = 1.0;   /* URDF <contact> friction of the lower legs is 1.0 */
     }
     /* support vertex: lowest hull vertex in the world (plane normal +z) */
@@ -350,10 +348,10 @@ static int collide_manifolds(oracle_env* E, int ei, const kin_t* K, cpoint_t* cp
       const double z = R[6] * H->v[i][0] + R[7] * H->v[i][1] + R[8] * H->v[i][2];
       if (z < zb) { zb = z; best = i; }
     }
-    const double dist = zb + K->o[l][2] - E->opt_hull_margin;
+    const double dist = zb + K->o[l][2] - E->cfg.collision_margin;
     if (dist < thr) {
       /* localA = link-frame coordinates of (vertex - margin * normal): what btManifoldResult stores as m_localPointA */
-      double down[3] = {0, 0, -E->opt_hull_margin}, dl[3], loc[3], wA[3];
+      double down[3] = {0, 0, -E->cfg.collision_margin}, dl[3], loc[3], wA[3];
       m3tmulv(dl, R, down);
       for (int k = 0; k < 3; k++) loc[k] = H->v[best][k] + dl[k];
       m3mulv(wA, R, loc); v3add(wA, wA, K->o[l]);
@@ -790,7 +788,7 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   E->last_counts = calloc((size_t)num_envs * 4, sizeof *E->last_counts);
   E->man = calloc((size_t)num_envs * NL_MAX, sizeof *E->man);
   E->iter_hist = calloc((size_t)num_envs, sizeof *E->iter_hist);
-  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_prim_margin = 0; E->opt_break_scale = 1; E->opt_hull_margin = HULL_MARGIN;
+  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_break_scale = 1;
   E->hulls = cfg->robot == SOLORL_ROBOT_SOLO12 ? ORACLE_HULLS_SOLO12 : ORACLE_HULLS_SOLO8;
   E->contact_model = 0; E->cap_contacts = 0; E->cap_limits = 0; E->manifold_links = ~0u;
   if (getenv("ORACLE_MANIFOLD_LINKS")) E->manifold_links = (unsigned)strtoul(getenv("ORACLE_MANIFOLD_LINKS"), NULL, 0);
@@ -809,9 +807,7 @@ int oracle_set_option(oracle_env* E, const char* name, double v) {
   if (!strcmp(name, "friction_skip_zero_normal")) E->opt_friction_skip = v != 0;
   else if (!strcmp(name, "gyro")) E->opt_gyro = v != 0;
   else if (!strcmp(name, "limit_split")) E->opt_limit_split = v != 0;
-  else if (!strcmp(name, "prim_margin")) E->opt_prim_margin = v;
   else if (!strcmp(name, "breaking_scale")) E->opt_break_scale = v;
-  else if (!strcmp(name, "hull_margin")) E->opt_hull_margin = v;
   else return -1;
   return 0;
 }

@@ -35,7 +35,7 @@ class SoloConfig(C.Structure):
         ("linear_slop", C.c_double), ("warmstart", C.c_double), ("damping", C.c_double),
         ("max_velocity", C.c_double), ("joint_limit", C.c_double), ("goal_radius", C.c_double),
         ("treadmill_offset", C.c_double), ("treadmill_half_width", C.c_double), ("treadmill_friction", C.c_double),
-        ("solver_residual_threshold", C.c_double), ("contact_erp", C.c_double),
+        ("solver_residual_threshold", C.c_double), ("contact_erp", C.c_double), ("collision_margin", C.c_double),
     ]
 
     @property
@@ -97,6 +97,7 @@ def default_config(robot=ROBOT_SOLO12, task=TASK_WALK):
     c.solver_residual_threshold = 1e-7      # K7: PyBullet's solverResidualThreshold, see include/solorl.h
     # [K] ledger: Bullet's implicit friction cone and PyBullet's contact ERP (m_erp2 = 0.08); rounds 1-3: pyramid, 0.2
     c.friction_model, c.contact_erp = FRICTION_CONE, 0.08
+    c.collision_margin = 0.001              # Bullet's margin around URDF hulls [K6]; rounds 1-3: the bare primitives (0)
     return c
 
 
@@ -148,7 +149,7 @@ def config_from_dict(d, **overrides):
         c.kp, c.kd = float(gains[0]), float(gains[1])
     for k in ("hold_torque", "use_urdf_inertia", "solver_iterations", "disable_termination", "settle_min",
               "settle_max", "precision", "warmstart", "erp", "damping", "reward_dt", "goal_radius", "treadmill_offset",
-              "treadmill_half_width", "treadmill_friction", "solver_residual_threshold", "contact_erp", "friction_model"):
+              "treadmill_half_width", "treadmill_friction", "solver_residual_threshold", "contact_erp", "friction_model", "collision_margin"):
         if k in d:
             v = d[k]
             if k == "friction_model" and isinstance(v, str):

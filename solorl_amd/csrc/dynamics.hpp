@@ -102,6 +102,8 @@ template <typename T> struct PhysParams {
   T tm_hw, tm_mu;              // treadmill strip (include/solorl.h treadmill_*): half width, friction factor
   T resid_thr;                 // sqrt(solver_residual_threshold): velocity-level change below which a solve stops (K7); < 0: never
   T cerp;                      // error reduction of the contact rows (solorl_config contact_erp = Bullet's m_erp2); erp above: joint-limit rows (m_erp)
+  T cmargin;                   // collision margin around every primitive (solorl_config collision_margin: Bullet's 1 mm around URDF hulls): a shape
+                               // swept by a sphere of that radius has its support point the margin further down -- P.z -= cmargin in this world-aligned frame
   // the switches share one word (the struct travels to every non-inlined phase function in argument VGPRs: four separate ints cost the
   // collision front its last free registers)
   int mode;
@@ -445,7 +447,7 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     constexpr int p = decltype(pc)::value;
     constexpr solorl_prim_data PR = RB::MD.prims[p];
     static_assert(PR.link == 0 && PR.axis == -1, "base primitives are points");
-    dist[p] = st.pos.z + R0.c0.z * T(PR.center[0]) + R0.c1.z * T(PR.center[1]) + R0.c2.z * T(PR.center[2]);
+    dist[p] = st.pos.z - pp.cmargin + R0.c0.z * T(PR.center[0]) + R0.c1.z * T(PR.center[1]) + R0.c2.z * T(PR.center[2]);
     if (dist[p] < T(PR.margin)) mask |= 1 << p;
     if (pp.tm_on() && fabs(ty + R0.c0.y * T(PR.center[0]) + R0.c1.y * T(PR.center[1]) + R0.c2.y * T(PR.center[2])) <= pp.tm_hw) smask |= 1 << p;
   });
@@ -453,6 +455,7 @@ SNI void phase_detect(CH ch, const PhysParams<T> pp) {
     constexpr int L = decltype(lc)::value;
     V3<T> kneeP, footP, shP = mk(T(0), T(0), T(0));
     leg_prim_points<T, ROBOT, L>(R0, sn, cs, kneeP, footP, shP);
+    kneeP.z -= pp.cmargin; footP.z -= pp.cmargin; shP.z -= pp.cmargin;
     C.kneeP[L] = kneeP; C.footP[L] = footP; C.shP[L] = shP;
     if constexpr (RB::SHOULDER) {
       constexpr double ms_ = RB::MD.prims[20 + L].margin;
@@ -879,7 +882,8 @@ SD void base_solve(SubCtx<T, ROBOT>& C, const PhysParams<T> pp, const T* lam_pre
       if ((mask >> p) & 1) {
         const int cidx = __builtin_popcount(mask & ((1 << p) - 1));
         const int sn_ = nlt + cidx, sf_ = nlt + nc + 2 * cidx;
-        const V3<T> P = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
+        V3<T> P = mul(R0, mk(T(PR.center[0]), T(PR.center[1]), T(PR.center[2])));
+        P.z -= pp.cmargin;
         const T lam0 = pp.warm * (TEAMQ ? C.lamp[p] : lam_prev[(unsigned)p * nstride]);
         const T Z[3] = {T(0), T(0), T(0)};
         static_for<3>([&](auto dc) {
@@ -1263,6 +1267,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
         footP = disc_point(R, o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2]))), PRIMC(1, radius), PRIMC(1, halfw));
       Rp = R; op = o;
     });
+    kneeP.z -= pp.cmargin; footP.z -= pp.cmargin; shP.z -= pp.cmargin;
     C.kneeP[L] = kneeP; C.footP[L] = footP;
     const T dk = pz + kneeP.z, df = pz + footP.z;
     C.dist[12 + 2 * L] = dk; C.dist[13 + 2 * L] = df;
@@ -1296,6 +1301,7 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
     const T mg = T(PA.margin);
     bfric = T(PA.friction);
     bP = mul(R0, mk(cx, cy, cz));
+    bP.z -= pp.cmargin;
     bdist = pz + bP.z;
     C.dist[p] = bdist;
     if (bdist < mg) bits |= 1 << p;

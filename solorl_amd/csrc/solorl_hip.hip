@@ -1021,7 +1021,7 @@ template <typename T> PhysParams<T> make_phys(const solorl_config& c) {
   p.iterations = c.solver_iterations;
   p.tm_hw = (T)c.treadmill_half_width; p.tm_mu = (T)c.treadmill_friction;
   p.resid_thr = c.solver_residual_threshold > 0 ? (T)sqrt(c.solver_residual_threshold) : T(-1);
-  p.cerp = (T)c.contact_erp;
+  p.cerp = (T)c.contact_erp; p.cmargin = (T)c.collision_margin;
   p.set_mode(true, c.use_urdf_inertia != 0, c.friction_model == SOLORL_FRICTION_CONE, c.use_treadmill != 0);
   return p;
 }
@@ -1161,6 +1161,7 @@ int check_cfg(const solorl_config* c) {
   if (!(c->solver_residual_threshold >= 0)) return fail(SOLORL_ERR_INVALID, "solver_residual_threshold must be >= 0");
   if (c->friction_model != SOLORL_FRICTION_PYRAMID && c->friction_model != SOLORL_FRICTION_CONE) return fail(SOLORL_ERR_INVALID, "friction_model must be pyramid or cone");
   if (!(c->contact_erp >= 0 && c->contact_erp <= 1) || !(c->erp >= 0 && c->erp <= 1)) return fail(SOLORL_ERR_INVALID, "erp / contact_erp must lie in [0, 1]");
+  if (!(c->collision_margin >= 0 && c->collision_margin <= 0.01)) return fail(SOLORL_ERR_INVALID, "collision_margin must lie in [0, 0.01] m");
   if (c->precision != SOLORL_PRECISION_F32 && c->precision != SOLORL_PRECISION_F64) return fail(SOLORL_ERR_INVALID, "bad precision");
   return 0;
 }
@@ -1229,6 +1230,7 @@ int solorl_default_config(solorl_config* c, int robot, int task) {
   c->joint_limit = 10.0; c->goal_radius = 2.0;
   c->use_treadmill = 0; c->treadmill_offset = 0.49; c->treadmill_half_width = 0.5; c->treadmill_friction = 0.5;
   c->solver_residual_threshold = 1e-7;     // PyBullet's solverResidualThreshold (K7), see include/solorl.h
+  c->collision_margin = 0.001;
   c->friction_model = SOLORL_FRICTION_CONE; c->contact_erp = 0.08;      // [K] ledger, DESIGN.md section 3 (rounds 1-3: pyramid, 0.2)
   return 0;
 }

@@ -18,7 +18,7 @@ static void run(solorl_env_state* s, const solorl_config* c, int apply_tau) {
   pp.damping = (T)c->damping; pp.vmax = (T)c->max_velocity; pp.qlim = (T)c->joint_limit; pp.inv_dt = (T)(1.0 / c->sim_dt);
   pp.iterations = c->solver_iterations;
   pp.resid_thr = c->solver_residual_threshold > 0 ? (T)std::sqrt(c->solver_residual_threshold) : T(-1);
-  pp.cerp = (T)c->contact_erp;
+  pp.cerp = (T)c->contact_erp; pp.cmargin = (T)c->collision_margin;
   pp.set_mode(true, c->use_urdf_inertia != 0, c->friction_model == SOLORL_FRICTION_CONE, c->use_treadmill != 0);
   pp.tm_hw = (T)c->treadmill_half_width; pp.tm_mu = (T)c->treadmill_friction;
   SubCtx<T, ROBOT> C;

@@ -118,6 +118,11 @@ def test_step_matches_oracle_resynced(gpu_device, robot, task, control):
         done_mismatch += int((done != odone).sum())
         for i in range(N):
             sg, so = env.get_state(i), orc.get_state(i)
+            if bool(done[i]) != bool(odone[i]):
+                # the two may only disagree AT a termination threshold: the side that lives on sits within 1e-4 of the fall height
+                # z = 0.05 (baseEnv.py:169) or of the goal radius 0.5 (solo.py:270)
+                live = so if done[i] else sg
+                assert abs(live.pos[2] - 0.05) < 1e-4 or (task == TASK_POINTGOAL and abs(live.potential - 0.5) < 1e-4), (i, t, live.pos[2], live.potential)
             if done[i] or odone[i]:
                 continue
             dq_all.append(np.abs(np.array(sg.q)[:n] - np.array(so.q)[:n]).max())
@@ -129,7 +134,7 @@ def test_step_matches_oracle_resynced(gpu_device, robot, task, control):
     dq_all = np.array(dq_all)
     check_parity_stats("step_resynced/robot%d_task%d_control%d" % (robot, task, control), dq_all)
     assert np.median(dq_all) < 1e-4, np.median(dq_all)
-    assert np.percentile(dq_all, 90) < 1e-3 + 5e-3 * (control == CONTROL_PD), np.percentile(dq_all, 90)
+    assert np.percentile(dq_all, 90) < 1e-3, np.percentile(dq_all, 90)         # (measured p90: 1e-6 .. 2e-6, tests/golden/parity_measured.json)
     assert np.median(dr_all) < 1e-3 and np.median(dobs_all) < 1e-3
     assert done_mismatch <= 2 and mask_mismatch <= 0.02 * len(dq_all)
 

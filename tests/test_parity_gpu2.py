@@ -5,7 +5,6 @@
   * the pointgoal goal-reached / bonus / resample branch and pointgoal-timeout-is-failure on the HIP path;
   * SURVEY.md 8(d)'s parity input verbatim, with the divergence horizon of the fp32 and fp64 engines read against
     the oracle's own horizon under a 1e-12 perturbation (fixture walk_torque_traj.npz);
-  * fp32 outliers of the resynced comparison are the states the fp64 engine ALSO amplifies (non-convergent PGS);
   * curriculum under HIP-graph replay;
   * the treadmill strip (configs/basic.yaml unmodified);
   * the engine's finished-episode accumulators vs the per-step info tensors and vs the oracle.
@@ -69,7 +68,7 @@ def test_config5_pd_path_resynced_vs_oracle(gpu_device):
     dq = np.array(dq)
     assert timeouts >= 0.4 * N
     check_parity_stats("config5_pd_path", dq)
-    assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 6e-3, (np.median(dq), np.percentile(dq, 90))
+    assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 1e-3, (np.median(dq), np.percentile(dq, 90))      # (measured p90 2e-6)
     assert np.median(drew) < 1e-3 and np.median(dobs) < 1e-3
 
 
@@ -99,8 +98,8 @@ def test_config5_full_size_8192_envs(gpu_device):
         assert st["episodes"] == int(n_done.sum()) and st["episode_length"] <= 50.0
         outs.append((o.clone(), r.clone(), n_done.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
-    # (a 6144-env shard: above 4096 envs the engine uses the plain sweep, below it the pipelined one -- same sums, other
-    # association -- so bitwise equality holds between batches on the same side; SOLORL_PGS_PIPE pins one variant)
+    # (the default solve -- PyBullet's residual exit -- is ONE sweep variant at every batch size, so a shard equals its slice bitwise
+    # whatever the two sizes; only with solver_residual_threshold = 0 does the variant depend on the grid, see test_fixed_sweep_variants_vs_oracle)
     off = N // 4
     env_a = SoloVecEnv(c, N, device="cuda:0", seed=4)
     env_b = SoloVecEnv(c, N - off, device="cuda:0", seed=4, env_id_offset=off)
@@ -166,14 +165,14 @@ def test_pointgoal_timeout_is_a_failure(gpu_device):
 def test_walk_torque_parity_input_divergence_horizon(gpu_device):
     """SURVEY.md 8(d) parity run verbatim on the HIP engine (see tests/test_host_harness.py for the regime: the robot
     is on the ground after 20 steps and the fp64 oracle itself, perturbed by 1e-12 rad, leaves the 1e-3 rad band after
-    `oracle_self_horizon` = 20 steps -- 61 with round 2's model; Bullet's residual exit and limit rule are step functions of the state).  Divergence horizon = first control step with max |dq| > 1e-3 rad.
+    `oracle_self_horizon` = 75 steps with round 4's friction cone -- 20 with round 3's pyramid, 61 with round 2's model: one e-fold every ~4 steps).  Divergence horizon = first control step with max |dq| > 1e-3 rad.
     Actions cross the boundary as float32 (agents/ppo/envs.py:190-192 in the reference as well), so the engines are
     compared with the oracle driven by the SAME float32-rounded actions; that rounding alone (3e-8 relative on the
     torques) moves the oracle off its own float64-action fixture within a couple of dozen steps."""
     from oracle.oracle_py import Oracle
     g = np.load(os.path.join(GOLDEN, "walk_torque_traj.npz"))
     self_h = int(g["oracle_self_horizon"])
-    T = 120
+    T = 130
     acts32 = np.stack([walk_action(t).astype(np.float32) for t in range(T)])
     o64 = Oracle(walk_cfg(), 1, seed=1); o64.reset()
     o32 = Oracle(walk_cfg(), 1, seed=1); o32.reset()
@@ -197,54 +196,11 @@ def test_walk_torque_parity_input_divergence_horizon(gpu_device):
         assert max(dq[:10]) < (1e-9 if name == "f64" else 5e-4)
     print("divergence horizons (control steps): oracle self (1e-12 perturbation) %d, oracle under float32 action rounding %d, "
           "engine fp64 %d, engine fp32 %d" % (self_h, h_round, hor["f64"], hor["f32"]))
-    assert hor["f64"] >= self_h - 5, hor  # as long as the oracle's own horizon (20), within the scatter of a chaotic run
-    assert hor["f32"] >= 12, hor
+    assert hor["f64"] >= self_h - 20, hor  # as long as the oracle's own horizon (75), within the scatter of a chaotic run
+    assert hor["f32"] >= 18, hor           # the same growth rate from fp32 rounding instead of 1e-12: ~25 steps (g++ build of the kernel math: 25)
 
 
-def test_fp32_outliers_are_states_the_fp64_engine_amplifies_too(gpu_device):
-    """The resynced comparison allows a few large per-step errors because 50 sweeps of box-friction PGS do not converge
-    in some multi-contact states.  Shown here rather than assumed: the fp32 engine, the fp64
-    engine and the oracle all step from the SAME (float32-representable) state.  The fp64 engine's error is 1e-15 for
-    99 % of the samples; the states where fp32 is off by > 1e-3 rad are, almost one for one, the < 1 % of states where
-    the fp64 engine's own rounding is amplified by 100x or more (measured: 28 of 29 outliers, against 0.7 % of all
-    samples), and where fp64 is quiet fp32 stays inside the north-star tolerance (all but ~1 in 5000: a contact
-    flipping at its threshold in fp32 only)."""
-    c32 = cfg_for(ROBOT_SOLO12, TASK_WALK)
-    c64 = cfg_for(ROBOT_SOLO12, TASK_WALK, precision=PRECISION_F64)
-    N = 128
-    env32, orc = make(c32, N, seed=3)
-    env64, _ = make(c64, N, seed=3)
-    env32.reset(); env64.reset(); orc.reset()
-    rng = np.random.default_rng(0)
-    e32, e64 = [], []
-    for t in range(40):
-        for i in range(N):
-            s = env32.get_state(i)
-            orc.set_state(i, s); env64.set_state(i, s)
-        a = rng.uniform(-1.2, 1.2, size=(N, 12)).astype(np.float32) * (0.3 if t < 15 else 1.0)
-        ta = torch.from_numpy(a).cuda()
-        _, _, d32, _ = env32.step(ta); _, _, d64, _ = env64.step(ta); _, _, od, _ = orc.step(a.astype(np.float64))
-        d32 = d32.cpu().numpy(); d64 = d64.cpu().numpy()
-        for i in range(N):
-            if d32[i] or d64[i] or od[i]:
-                continue
-            qo = np.array(orc.get_state(i).q)
-            e32.append(np.abs(np.array(env32.get_state(i).q) - qo).max())
-            e64.append(np.abs(np.array(env64.get_state(i).q) - qo).max())
-    e32, e64 = np.array(e32), np.array(e64)
-    med64 = np.median(e64)
-    out32 = e32 > 1e-3
-    amplified = e64 > 1e2 * med64
-    quiet = e64 < 1e1 * med64
-    print("samples %d, fp32 outliers %d (%.2f %%), median e64 %.1e, amplified (e64 > 100 x median) %.2f %% of all samples and "
-          "%d of the %d outliers; quiet states with e32 > 1e-3: %d of %d" % (
-              len(e32), out32.sum(), 100 * out32.mean(), med64, 100 * amplified.mean(), (amplified & out32).sum(), out32.sum(),
-              (quiet & out32).sum(), quiet.sum()))
-    assert med64 < 1e-13 and len(e32) > 3000
-    assert 0 < out32.sum() < 0.02 * len(e32)
-    assert amplified.mean() < 0.03                                   # amplification is rare ...
-    assert (amplified & out32).sum() >= 0.85 * out32.sum()           # ... and it is where the fp32 outliers are
-    assert quiet.sum() > 0.8 * len(e32) and (quiet & out32).sum() <= 0.001 * quiet.sum() + 1
+# (the fp32-outlier census lives in tests/test_parity_gpu3.py: test_error_tail_* -- every resynced workload, strict)
 
 
 # ------------------------------------------------------------------------------------------------ curriculum + graphs
@@ -368,7 +324,7 @@ def test_episode_stat_accumulators(gpu_device):
             assert abs(mine - theirs) < 0.1 * abs(theirs) + 0.05, (name, mine, theirs)
 
 
-# ------------------------------------------------------------------------------------------------ K7 early exit (opt-in)
+# ------------------------------------------------------------------------------------------------ K7: fixed sweeps (option) and the residual exit (default)
 @pytest.mark.parametrize("warmstart", [0.0, 0.85])
 def test_fixed_sweep_variants_vs_oracle(gpu_device, warmstart):
     """solver_residual_threshold = 0 (fixed 50 sweeps, round 2's default): above one wavefront per SIMD (more than 4096 envs on an
@@ -412,7 +368,7 @@ def test_fixed_sweep_variants_vs_oracle(gpu_device, warmstart):
 
 @pytest.mark.parametrize("team", [1, 0])
 def test_residual_threshold_early_exit_vs_oracle(gpu_device, team):
-    """solver_residual_threshold = 1e-7 (PyBullet's solverResidualThreshold, SURVEY Appendix B K7; opt-in): every env's
+    """solver_residual_threshold = 1e-7 (PyBullet's solverResidualThreshold, SURVEY Appendix B K7; the default since round 3): every env's
     solve ends after the first sweep within the threshold -- per env, also when the four envs of a team-mode wavefront
     finish after different sweeps.  Resynced against the oracle running the same rule; team mode (default) and lane mode."""
     from solorl_amd.vec_env import SoloVecEnv

@@ -31,15 +31,13 @@ from solorl_amd.config import (default_config, ROBOT_SOLO8, ROBOT_SOLO12, TASK_W
 
 # name -> (config overrides, oracle options, contact model, what it restates)
 VARIANTS = [
-    ("baseline", {}, {}, 0, "the defaults of solorl_default_config"),
+    ("baseline", {}, {}, 0, "the defaults of solorl_default_config: friction cone, contact ERP 0.08, collision margin 1 mm, K1-K11 as adopted"),
     ("friction pyramid", {"friction_model": FRICTION_PYRAMID}, {}, 0, "rounds 1-3: each friction row clamped on its own, Gauss-Seidel between the two"),
-    ("friction cone", {"friction_model": FRICTION_CONE}, {}, 0, "Bullet's implicit cone (resolveConeFrictionConstraintRows)"),
     ("contact erp 0.2", {"contact_erp": 0.2}, {}, 0, "btContactSolverInfo's own m_erp2 default (rounds 1-3)"),
-    ("contact erp 0.08", {"contact_erp": 0.08}, {}, 0, "PyBullet's physics server: m_erp2 = 0.08"),
-    ("pyramid + erp 0.2 (round 3)", {"friction_model": FRICTION_PYRAMID, "contact_erp": 0.2}, {}, 0, "round 3's pair"),
-    ("cone + erp 0.08", {"friction_model": FRICTION_CONE, "contact_erp": 0.08}, {}, 0, "what PyBullet is believed to run"),
+    ("round 3: pyramid, erp 0.2, margin 0", {"friction_model": FRICTION_PYRAMID, "contact_erp": 0.2, "collision_margin": 0.0}, {}, 0, "round 3's defaults"),
     ("pyramid: skip friction at zero normal", {"friction_model": FRICTION_PYRAMID}, {"friction_skip_zero_normal": 1}, 0, "`if (totalImpulse > 0)` of the pyramid branch"),
-    ("primitive margin 1 mm", {}, {"prim_margin": 0.001}, 0, "URDF hulls carry a 1 mm collision margin; the primitives carry none"),
+    ("collision margin 0", {"collision_margin": 0.0}, {}, 0, "the bare primitives (rounds 1-3) instead of Bullet's 1 mm margin around URDF hulls"),
+    ("collision margin 2 mm", {"collision_margin": 0.002}, {}, 0, ""),
     ("breaking threshold x 0.5", {}, {"breaking_scale": 0.5}, 0, "gContactBreakingThreshold 0.01 instead of 0.02"),
     ("breaking threshold x 2", {}, {"breaking_scale": 2.0}, 0, "0.04"),
     ("damping 0", {"damping": 0.0}, {}, 0, "btMultiBody linear / angular damping 0 instead of 0.04 (K3)"),
@@ -53,7 +51,7 @@ VARIANTS = [
     ("200 solver sweeps", {"solver_iterations": 200}, {}, 0, "numSolverIterations 200 instead of 50"),
     ("residual exit off", {"solver_residual_threshold": 0.0}, {}, 0, "always 50 sweeps (rounds 1-2)"),
     ("hull manifolds (K6)", {}, {}, 1, "Bullet's hull-vs-plane persistent manifolds instead of the primitives (oracle contact_model 1)"),
-    ("hull manifolds, margin 0", {}, {"hull_margin": 0.0}, 1, "the same without the 1 mm hull margin"),
+    ("hull manifolds, margin 0", {"collision_margin": 0.0}, {}, 1, "the same without the 1 mm hull margin"),
 ]
 
 
