@@ -22,6 +22,8 @@
  *                             pre-activation gradient (what `loss.backward()` computes before the weight-gradient GEMMs)
  *   solorl_ppo_grad_stage2 <- the weight-gradient products of that backward pass, written into the parameters' gradients
  *   solorl_ppo_clip_adam   <- agents/ppo/ppo.py:75-77 (clip_grad_norm_ + optimizer.step) on the MLP's 13 parameter tensors
+ *   solorl_step_act        <- agents/ppo/train.py:84-88: the rollout's pair `actor_critic.act(obs)` + `envs.step(action)` as ONE launch
+ *                             (the policy is evaluated on each observation by the wavefront that has just produced it)
  *   solorl_get_state / solorl_set_state / solorl_get_property : no reference counterpart (parity-test hooks, run records)
  *   solorl_destroy         <- agents/ppo/envs.py:129-135 (close)
  *
@@ -298,6 +300,19 @@ typedef struct solorl_adam_state {
                        * all-reduce of the flat bucket (data-parallel mean); <= 0 is read as 1 */
 } solorl_adam_state;
 int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* g, const solorl_adam_state* a, int device_id, void* stream);
+
+/* solorl_step followed by Policy.act (agents/ppo/policy.py:33-49) on the NEW observation of every env, in the same launch: value_out
+ * [N], action_out [N][A] = mean + exp(logstd) * noise (noise [N][A]: the caller's standard-normal draw; NULL: action = mean),
+ * logp_out [N].  What the reference's rollout loop does with two calls per step (agents/ppo/train.py:84-88) and solorl_policy_act +
+ * solorl_step do with two launches.  Why one: at 4096 envs per GPU the step launch lasts as long as its slowest wavefront while the
+ * mean wavefront is done in half that time; each wavefront evaluates the policy for its own four envs as soon as their observations
+ * exist, so the policy costs no launch of its own.  Needs the engine's defaults (fp32, team mode, no contact-count sorting), hidden
+ * = 64, obs_dim = this env's observation size and a multiple of 4 (one history level), 16-byte aligned weight matrices; otherwise
+ * SOLORL_ERR_INVALID and the caller keeps the two-call form.  Outputs equal solorl_policy_act's on the same rows up to the order
+ * of the f32 sums (tested: 2e-6). */
+int solorl_step_act(solorl_env* env, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,
+                    const solorl_info_soa* info_out, const solorl_policy_params* p, const float* noise, float* value_out,
+                    float* action_out, float* logp_out, void* stream);
 
 const char* solorl_last_error(void);
 const char* solorl_version(void);

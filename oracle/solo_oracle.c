@@ -135,6 +135,7 @@ struct oracle_env {
   int opt_gyro;                  /* 1 (default): gyroscopic term w x I w (btMultiBody::m_useGyroTerm) */
   int opt_limit_split;           /* 1: a joint more than 0.04 rad beyond its limit loses the positional term (btMultiBodyJointLimitConstraint with
                                   * m_splitImpulse on and no split-impulse pass for multibodies) and uses erp2 */
+  int opt_manifold_persist;      /* manifold model: 1 (default) Bullet's persistent <= 4-point cache; 0: only this step's support vertex (ablation: geometry vs caching) */
   double opt_break_scale;        /* scale of every contact-breaking threshold (gContactBreakingThreshold 0.02) */
   int64_t (*iter_hist)[ITER_HIST]; /* [N][ITER_HIST]: sub-steps that had rows, by the number of PGS sweeps they ran */
 };
@@ -294,7 +295,18 @@ static double prim_point(const oracle_env* E, const kin_t* K, int p, double* P) 
      * that points down, reaching the face at a tilt of asin(DISC_RIM) -- so a link lying on its side rests half a thickness lower
      * than its mid-plane, as its hull does, while an upright leg keeps ONE smooth contact point (a sharp rim would make the point
      * jump by the full thickness whenever the roll changes sign) */
-    if (pr->halfw > 0) { double w = da / DISC_RIM; w = w > 1 ? 1 : (w < -1 ? -1 : w); loc[pr->axis] += pr->halfw * w; }
+    if (pr->nring > 1) {
+      /* round 4 (K6): a body of revolution given by its profile rings (the feet: a 4 mm tread of radius 16 mm chamfered to 11.7 mm at
+       * the faces, tools/compile_model.py ring_profile): the support point lies on the ring maximising r_i |d_perp| + y_i |d_axis|;
+       * ring 0, the tread, is crossed smoothly as above, the others are the hull's own edges */
+      const double s = sqrt(v3dot(d, d) + DISC_EPS2), a = fabs(da);
+      int best = 0; double vb = pr->ring_r[0] * s + pr->ring_y[0] * a;
+      for (int i = 1; i < pr->nring; i++) { const double vi = pr->ring_r[i] * s + pr->ring_y[i] * a; if (vi > vb) { vb = vi; best = i; } }
+      v3cpy(loc, pr->center);
+      v3axpy(loc, pr->ring_r[best] / s, d);
+      double w = a / DISC_RIM; w = w > 1 ? 1 : w;
+      loc[pr->axis] += (da < 0 ? -1.0 : 1.0) * (best == 0 ? pr->ring_y[0] * w : pr->ring_y[best]);
+    } else if (pr->halfw > 0) { double w = da / DISC_RIM; w = w > 1 ? 1 : (w < -1 ? -1 : w); loc[pr->axis] += pr->halfw * w; }
   }
   m3mulv(P, K->R[l], loc); v3add(P, P, K->o[l]);
   return P[2];
@@ -331,6 +343,7 @@ static int collide_manifolds(oracle_env* E, int ei, const kin_t* K, cpoint_t* cp
   for (int l = 0; l < E->nl; l++) {
     if (!((E->manifold_links >> l) & 1u)) continue;
     manifold_t* m = &E->man[(size_t)ei * NL_MAX + l];
+    if (!E->opt_manifold_persist) m->n = 0;
     const oracle_hull* H = &E->hulls[l];
     double thr = 0, fric = 0.5;
     int have = 0;
@@ -788,7 +801,7 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   E->last_counts = calloc((size_t)num_envs * 4, sizeof *E->last_counts);
   E->man = calloc((size_t)num_envs * NL_MAX, sizeof *E->man);
   E->iter_hist = calloc((size_t)num_envs, sizeof *E->iter_hist);
-  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_break_scale = 1;
+  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_break_scale = 1; E->opt_manifold_persist = 1;
   E->hulls = cfg->robot == SOLORL_ROBOT_SOLO12 ? ORACLE_HULLS_SOLO12 : ORACLE_HULLS_SOLO8;
   E->contact_model = 0; E->cap_contacts = 0; E->cap_limits = 0; E->manifold_links = ~0u;
   if (getenv("ORACLE_MANIFOLD_LINKS")) E->manifold_links = (unsigned)strtoul(getenv("ORACLE_MANIFOLD_LINKS"), NULL, 0);
@@ -808,6 +821,7 @@ int oracle_set_option(oracle_env* E, const char* name, double v) {
   else if (!strcmp(name, "gyro")) E->opt_gyro = v != 0;
   else if (!strcmp(name, "limit_split")) E->opt_limit_split = v != 0;
   else if (!strcmp(name, "breaking_scale")) E->opt_break_scale = v;
+  else if (!strcmp(name, "manifold_persist")) E->opt_manifold_persist = v != 0;
   else return -1;
   return 0;
 }

@@ -62,7 +62,8 @@ void oracle_set_caps(oracle_env* e, int max_contacts, int max_limits);
 void oracle_set_contact_model(oracle_env* e, int model);
 /* [K] ledger options (tools/k_ledger.py): Bullet defaults the reference inherits that are NOT solorl_config fields,
  * switchable on the oracle so that their effect can be measured.  Names: "friction_skip_zero_normal" (0), "gyro" (1), "limit_split" (0),
- * "breaking_scale" (1).  Returns 0, or -1 for an unknown name. */
+ * "breaking_scale" (1), "manifold_persist" (1; 0 = contact model 1 keeps only the current support vertex of each hull).  Returns 0, or -1
+ * for an unknown name. */
 int oracle_set_option(oracle_env* e, const char* name, double value);
 /* sub-steps that had constraint rows, by the number of PGS sweeps they ran (128 bins, summed over envs; clear != 0 zeroes the counts) */
 void oracle_iteration_histogram(oracle_env* e, int64_t* out, int clear);

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
            "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state", "solorl_get_property",
            "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_ppo_clip_adam", "solorl_last_error", "solorl_version",
-           "solorl_abi_version")
+           "solorl_abi_version", "solorl_step_act")
 
 
 class PolicyParams(C.Structure):            # solorl_policy_params
@@ -66,6 +66,8 @@ def lib():
         L.solorl_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.solorl_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoSoA), C.c_void_p]
         L.solorl_get_observation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.solorl_step_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoSoA), C.POINTER(PolicyParams), C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.solorl_increment_curriculum.argtypes = [C.c_void_p, C.c_double]
         L.solorl_get_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(EnvState)]
         L.solorl_set_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(EnvState)]

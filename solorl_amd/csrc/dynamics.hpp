@@ -269,6 +269,20 @@ template <typename T> SD V3<T> disc_point(const M3<T>& R, V3<T> C, T radius, T h
   w = w > T(1) ? T(1) : (w < T(-1) ? T(-1) : w);
   return P + R.c1 * (halfw * w);
 }
+// Body of revolution about the link's y axis given by NR profile rings (ring_y[i] >= 0 from the centre plane C, ring_r[i]; model table,
+// tools/compile_model.py ring_profile; the feet): the support point lies on the ring maximising r_i |d_perp| + y_i |d_axis|.  Ring 0, the
+// tread, is crossed smoothly like disc_point's thickness; the others are the hull's own edges.  (oracle: prim_point)
+template <typename T, int NR> SD V3<T> ring_disc_point(const M3<T>& R, V3<T> C, const T (&ry)[NR], const T (&rr)[NR]) {
+  const T dx = -R.c0.z, dz = -R.c2.z, dy = -R.c1.z;   // world-down in the link's axes
+  const T s2 = dx * dx + dz * dz + T(DISC_EPS2);
+  const T is = rsqrt_fast(s2), s = s2 * is, a = fabs(dy);
+  T aw = a * T(1.0 / DISC_RIM); aw = aw > T(1) ? T(1) : aw;
+  T vb = rr[0] * s + ry[0] * a, r = rr[0], y = ry[0] * aw;
+#pragma unroll
+  for (int i = 1; i < NR; i++) { const T vi = rr[i] * s + ry[i] * a; const bool b = vi > vb; vb = b ? vi : vb; r = b ? rr[i] : r; y = b ? ry[i] : y; }
+  const T sc = r * is;
+  return C + R.c0 * (dx * sc) + R.c2 * (dz * sc) + R.c1 * (dy < T(0) ? -y : y);
+}
 // the same for a disc about the link's x axis (shoulder housings)
 template <typename T> SD V3<T> disc_point_x(const M3<T>& R, V3<T> C, T radius) {
   T dy = -R.c1.z, dz = -R.c2.z;                       // world-down expressed in the link's y,z
@@ -344,7 +358,9 @@ SD void leg_prim_points(const M3<T>& R0, const T* sn, const T* cs, V3<T>& kneeP,
       constexpr solorl_prim_data PR = RB::MD.prims[13 + 2 * L];
       static_assert(FT.jtype == 1 && PR.link == L0 + NJ && PR.axis == 1 && PR.center[0] == 0.0 && PR.center[1] == 0.0 &&
                     PR.center[2] == 0.0, "foot primitive layout");
-      footP = disc_point(R, addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]), T(PR.radius), T(PR.halfw));
+      static_assert(PR.nring == 4, "foot primitive: four profile rings (tools/compile_model.py)");
+      const T fy[4] = {T(PR.ring_y[0]), T(PR.ring_y[1]), T(PR.ring_y[2]), T(PR.ring_y[3])}, fr[4] = {T(PR.ring_r[0]), T(PR.ring_r[1]), T(PR.ring_r[2]), T(PR.ring_r[3])};
+      footP = ring_disc_point<T, 4>(R, addc(o, R, FT.jorigin[0], FT.jorigin[1], FT.jorigin[2]), fy, fr);
     }
   });
 }
@@ -1264,7 +1280,12 @@ SNI_SCALAR void phase_front_team(CH ch, const PhysParams<T> pp, const LDS lds, i
       if constexpr (k == NJ - 2)   // knee disc sits on the upper leg
         kneeP = disc_point(R, o + mul(R, mk(PRIMC(0, center[0]), PRIMC(0, center[1]), PRIMC(0, center[2]))), PRIMC(0, radius), PRIMC(0, halfw));
       if constexpr (k == NJ - 1)   // foot: fixed child of the last link, primitive centred on its origin
-        footP = disc_point(R, o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2]))), PRIMC(1, radius), PRIMC(1, halfw));
+      {
+        static_assert(RB::MD.prims[13].nring == 4, "foot primitive: four profile rings (tools/compile_model.py)");
+        const T fy[4] = {PRIMC(1, ring_y[0]), PRIMC(1, ring_y[1]), PRIMC(1, ring_y[2]), PRIMC(1, ring_y[3])};
+        const T fr[4] = {PRIMC(1, ring_r[0]), PRIMC(1, ring_r[1]), PRIMC(1, ring_r[2]), PRIMC(1, ring_r[3])};
+        footP = ring_disc_point<T, 4>(R, o + mul(R, mk(LEGC(NJ, jorigin[0]), LEGC(NJ, jorigin[1]), LEGC(NJ, jorigin[2]))), fy, fr);
+      }
       Rp = R; op = o;
     });
     kneeP.z -= pp.cmargin; footP.z -= pp.cmargin; shP.z -= pp.cmargin;
@@ -1546,7 +1567,7 @@ template <typename T> SD T half_swap(T x) {
 // One instantiation per slot set of the wave (LIM: the limit slot, NNS normal slots, NFS friction slots; teams
 // with fewer rows sweep null rows), so the slot sequence -- each slot's predecessor and successor, with
 // wrap-around between sweeps -- is static.  A lone wavefront issues a DEPENDENT instruction only every
-// ~8.5 cycles (16 after a DPP move; tools/dev/ubench/issue.hip) and Gauss-Seidel is one long dependency
+// ~8.5 cycles (16 after a DPP move; issue-rate microbenchmark of rounds 1-2, profiles/r02_notes.md) and Gauss-Seidel is one long dependency
 // chain, so the chain is cut down to the scalar clamp: the J'.acc reduction of the NEXT slot (multiplies +
 // DPP butterfly, 2/3 of a slot's latency) is started one slot early on accumulators that lack the current
 // slot's update, which is added back analytically through two more precomputed couplings,
@@ -1969,23 +1990,14 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   const bool ui = pp.urdf_inertia();     // (uniform) K2: URDF tensors instead of the box rule
   if (ui) phase_front_team<T, ROBOT, LDS, CH, true>(ch, pp, lds, t, valid, lead);
   else phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
-#ifdef SOLO_DUP_FRONT      // dev: run an idempotent phase twice -- the launch-time delta is that phase's true cost
-  phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
-#endif
   SOLO_PT(1);
   if (valid && t < 4) {                                                                     // four legs on four lanes
     if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t);
     else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
   }
-#ifdef SOLO_DUP_LEGS
-  if (valid && t < 4) phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
-#endif
   SOLO_PT(2);
   if (valid) team_sum_base<T, ROBOT, CH>(ch, t);
   SOLO_PT(3);
-#ifdef SOLO_DUP_BASE       // dev timing (tools/dev/dup_phase.sh); idempotent now that the leg sum is a separate step
-  if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
-#endif
   if (lead) phase_base_lead<T, ROBOT, LDS, CH>(ch, pp, lam_prev, nstride, lds);
   else if (!valid && t == 0) {   // idle team: no rows
     lds.hdr()[0] = T(0); lds.hdr()[LN] = T(0);
@@ -1994,9 +2006,6 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   if (valid) phase_legrates_team<T, ROBOT, LDS, CH>(ch, pp, lds, t);
   SOLO_PT(5);
   phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
-#ifdef SOLO_DUP_FINISH
-  phase_finish_team<T, ROBOT, LDS>(pp, lds, t);
-#endif
   SOLO_PT(6);
   phase_pgs_team<T, ROBOT, LDS>(pp.iterations, pp.warm != T(0), pp.resid_thr >= T(0), pp.pgs_pipe(), pp.cone(), lds, t);
   SOLO_PT(7);

@@ -92,11 +92,19 @@ enum { DYN_GOAL_RADIUS = 0, NDYN = 4 };
 
 enum { MODE_STEP = 0, MODE_SETTLE = 1 };
 
+// solorl_step_act: Policy.act on the observation a step has just written, by the wavefront that wrote it (policy_tail_team)
+struct PolicyTail {
+  const float *cw0, *cb0, *cw1, *cb1, *cw2, *cb2, *aw0, *ab0, *aw1, *ab1, *mw, *mb, *logstd;
+  const float* noise;                       // [N][A] standard-normal draw, or null (action = mean)
+  float *value, *action, *logp;             // [N], [N][A], [N]; value == null: no policy tail in this launch
+};
+
 struct Outputs {
   float* obs; float* rew; unsigned char* done;
   unsigned char *timeout, *success, *nan_reset; int* ep_len; float *ep_rew, *goals, *dr0, *dr1, *dr2, *dr3, *dr4;
   float* ep_stats;     // [SOLORL_EPSTAT_FIELDS][N] finished-episode accumulators (include/solorl.h), or null
   float* tau;          // [N][A] applied joint torques of this step (include/solorl.h applied_torque), or null
+  PolicyTail pol;
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -481,6 +489,84 @@ SD void team_current_state(const SubCtx<T, ROBOT>& C, int task, int D, int t, T 
 // the team leader, on values it reads from LDS.  Nothing but the six history values a lane needs for the observation deltas
 // stays in registers across the sub-steps (the round-1 version kept the env there: 56 spilled VGPRs per wavefront and step,
 // 11 MB of scratch write-back per launch against 5.7 MB of algorithmic traffic).
+// ---------------------------------------------------------------- Policy.act in the step kernel's tail (solorl_step_act)
+// agents/ppo/policy.py:33-49 on the MLP of :62-81 (two tanh MLPs obs -> 64 -> 64, critic head -> 1, actor head -> A, state-independent
+// log-std) for the env whose observation this team has just produced.  Why here: at 4096 envs the launch lasts as long as its slowest
+// wavefront while the MEAN wavefront is done after half that time, and the rollout's next launch -- the policy --
+// can only start when the launch has drained; computed by each wavefront for its own four envs the policy rides in that idle time and
+// a rollout step is ONE launch.  16 lanes per env: lane t owns hidden units 4t .. 4t+3 of both nets, activations are exchanged through
+// the (now dead) row storage in LDS, weights come from L2 as float4 rows (PyTorch layout); lanes 0..A-1 finish the actor head, lane 15
+// the critic head.  ~1700 instructions per wavefront (~3 us) against a 15 us kernel + launch gap.  O % 4 == 0 (one history level).
+constexpr float POL_HALF_LOG_2PI = 0.91893853320467274178f;
+constexpr unsigned POL_ENV_BYTES = 2496;     // per-env slice of the row storage (26 rows x 24 values x 4 B): obs <= 96, h1 128, h2 128 floats
+SD float pol_tanh(float x) { const float e = __expf(2.0f * x); return 1.0f - 2.0f * __frcp_rn(1.0f + e); }   // as solorl_ppo.hip tanh_fast
+typedef float nfloat4 __attribute__((ext_vector_type(4)));          // (native vector: HIP's float4 class cannot be read through an address-space pointer)
+typedef __attribute__((address_space(1))) const nfloat4 gfloat4;
+SD float pol_dot4(nfloat4 w, nfloat4 x, float acc) { return fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, acc)))); }
+template <int A>
+SD void policy_tail_team(const PolicyTail& P, int O, int col, int t, idx_t env, bool valid) {
+  float* const buf = reinterpret_cast<float*>(solo_smem + (unsigned)col * POL_ENV_BYTES);
+  const nfloat4* const obs4 = reinterpret_cast<const nfloat4*>(buf);
+  float* const h1 = buf + 96;              // [critic 64 | actor 64]
+  float* const h2 = buf + 224;
+  const int O4 = O >> 2;
+  float c[4], a[4];
+  {   // layer 1
+    gfloat4* wc = (gfloat4*)(P.cw0 + (size_t)(4 * t) * O);
+    gfloat4* wa = (gfloat4*)(P.aw0 + (size_t)(4 * t) * O);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { c[u] = P.cb0[4 * t + u]; a[u] = P.ab0[4 * t + u]; }
+#pragma unroll 4                                   // (32 weight loads in flight per batch: a lone wavefront has nothing else to hide their latency)
+    for (int k = 0; k < O4; k++) {
+      const nfloat4 x = obs4[k];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wc[u * O4 + k], x, c[u]); a[u] = pol_dot4(wa[u * O4 + k], x, a[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { h1[4 * t + u] = pol_tanh(c[u]); h1[64 + 4 * t + u] = pol_tanh(a[u]); }
+  }
+  TEAM_SYNC();
+  {   // layer 2
+    gfloat4* wc = (gfloat4*)(P.cw1 + (size_t)(4 * t) * 64);
+    gfloat4* wa = (gfloat4*)(P.aw1 + (size_t)(4 * t) * 64);
+    const nfloat4* xc = reinterpret_cast<const nfloat4*>(h1); const nfloat4* xa = reinterpret_cast<const nfloat4*>(h1 + 64);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { c[u] = P.cb1[4 * t + u]; a[u] = P.ab1[4 * t + u]; }
+#pragma unroll 8
+    for (int k = 0; k < 16; k++) {
+      const nfloat4 x = xc[k], y = xa[k];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wc[u * 16 + k], x, c[u]); a[u] = pol_dot4(wa[u * 16 + k], y, a[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { h2[4 * t + u] = pol_tanh(c[u]); h2[64 + 4 * t + u] = pol_tanh(a[u]); }
+  }
+  TEAM_SYNC();
+  // heads: lane t < A -> mean_t (and the action, its log-prob term), lane 15 -> value
+  static_assert(A < 15, "the critic head sits on lane 15");
+  float out = 0.f;
+  if (t < A || t == 15) {
+    gfloat4* w = (gfloat4*)(t == 15 ? P.cw2 : P.mw + (size_t)t * 64);
+    const nfloat4* x = reinterpret_cast<const nfloat4*>(t == 15 ? h2 : h2 + 64);
+    out = t == 15 ? P.cb2[0] : P.mb[t];
+#pragma unroll
+    for (int k = 0; k < 16; k++) out = pol_dot4(w[k], x[k], out);
+  }
+  float lp = 0.f, act = out;
+  if (t < A) {
+    const float ls = P.logstd[t];
+    const float nz = P.noise ? P.noise[(size_t)env * A + t] : 0.f;
+    act = out + __expf(ls) * nz;                                   // policy.py:41-45: mean + std * noise (noise null: the mean)
+    lp = -0.5f * nz * nz - ls - POL_HALF_LOG_2PI;                  // log N(action; mean, std) = sum over dims, z = noise
+  }
+  lp = team_sum16(lp);
+  if (valid) {
+    if (t < A) P.action[(size_t)env * A + t] = act;
+    if (t == 15) P.value[env] = out;
+    if (t == 0) P.logp[env] = lp;
+  }
+}
+
 template <typename T, int ROBOT>
 SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
                   const Layout& L, int N, const EnvParams& P, const PhysParams<T>& pp, const float* __restrict__ actions,
@@ -729,9 +815,12 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   T cso[HK];
   if (want_obs) team_current_state<T, ROBOT, HK>(C, P.task, L.D, t, cso);
   WT_STAMP(8);
+  bool with_policy = false;
+  if constexpr (sizeof(T) == 4) with_policy = want_obs && out.pol.value != nullptr;         // (uniform: a kernel argument)
   if (valid) {
     if (want_obs) {
       float* o = out.obs + env * (idx_t)(L.D * (1 + L.H));
+      float* ol = reinterpret_cast<float*>(solo_smem + (unsigned)col * POL_ENV_BYTES);       // the policy tail's copy (row storage: dead by now)
 #pragma unroll
       for (int k = 0; k < HK; k++) {
         const int d = t + 16 * k;
@@ -740,6 +829,11 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
           o[d] = (float)c;
           if (L.H >= 1) o[L.D + d] = (float)(c - hk0[k]);
           if (L.H == 2) o[2 * L.D + d] = (float)(c - hk1[k]);
+          if (with_policy) {
+            ol[d] = (float)c;
+            if (L.H >= 1) ol[L.D + d] = (float)(c - hk0[k]);
+            if (L.H == 2) ol[2 * L.D + d] = (float)(c - hk1[k]);
+          }
         }
       }
     }
@@ -747,6 +841,12 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
     for (int f = t; f < ((NPS + 3) & ~3); f += 16) sf[SX(L.pos + f, e, L.NF)] = f < NPS ? psv[f] : T(0);     // (whole sectors:
     sf[SX(L.goal + t, e, L.NF)] = t < NER ? C.erec[t] : T(0);                                                 //  the pads are written too)
     if (t < 3) si[SX(t, e, NI)] = C.irec[t];
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (with_policy) {
+      TEAM_SYNC();           // the observation copy, written by all lanes above
+      policy_tail_team<NQ>(out.pol, L.D * (1 + L.H), col, t, env, valid);
+    }
   }
   WT_STAMP(9);
 #ifdef SOLO_WAVE_TIMING
@@ -773,11 +873,14 @@ step_kernel(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf,
 // register budget is held to 256 (the heaviest sweep variants then keep a few callee-saved registers in scratch instead
 // of AGPRs).  A lone wavefront issues a VALU instruction every 4 cycles, the SIMD-32 one every 2: above 4096 envs per GPU
 // the second wavefront is what fills the issue slots (8192 envs: 0.326 -> 0.27 ms per step; 65 536: 29.5 -> 48.8 M env-steps/s).
+// The fp64 instantiation (the reference's arithmetic type; validation precision) is bounded to ONE wavefront per SIMD instead: its
+// workgroup needs 37 KB of LDS, so only four fit a CU anyway, and with the 512-entry register budget (256 VGPRs + 256 AGPRs) a value
+// that is a register PAIR stops spilling -- measured round 4 (profiles/r04_f64_ab.txt): 1.44 -> 0.55 ms per step at 4096 envs.
 #ifndef SOLO_WAVES_PER_SIMD
 #define SOLO_WAVES_PER_SIMD 2
 #endif
 template <typename T, int ROBOT>
-__global__ void __launch_bounds__(64, SOLO_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, sizeof(T) == 8 ? 1 : SOLO_WAVES_PER_SIMD)
 step_kernel_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict__ snf, const int* __restrict__ sni, int M,
                  Layout L, int N, EnvParams P, PhysParams<T> pp, const float* __restrict__ actions, Outputs out, int mode) {
   step_team<T, ROBOT>(sf, si, snf, sni, M, L, N, P, pp, actions, out, mode);
@@ -1384,6 +1487,34 @@ int solorl_step(solorl_env* h, const float* actions, float* obs_out, float* rewa
     HIP_TRY(hipGetLastError());
     std::swap(h->sf, h->sf2); std::swap(h->si, h->si2);
   }
+  return dispatch_step(h, h->sf, h->si, h->N, actions, o, MODE_STEP, (hipStream_t)stream);
+}
+
+int solorl_step_act(solorl_env* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out, const solorl_info_soa* info,
+                    const solorl_policy_params* p, const float* noise, float* value_out, float* action_out, float* logp_out, void* stream) {
+  if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
+  if (!p || !value_out || !action_out || !logp_out) return fail(SOLORL_ERR_INVALID, "solorl_step_act: null policy argument");
+  if (h->f64 || !h->team || h->sort) return fail(SOLORL_ERR_INVALID, "solorl_step_act needs the fp32 team-mode engine without contact-count sorting (the defaults)");
+  if (p->hidden != 64 || p->obs_dim != h->O || p->act_dim != h->n || (h->O & 3))
+    return fail(SOLORL_ERR_INVALID, "solorl_step_act: the policy must be the MLP of hidden size 64 on this env's observation / action sizes, obs_dim a multiple of 4");
+  const void* ptrs[] = {p->critic_w0, p->critic_b0, p->critic_w1, p->critic_b1, p->critic_w2, p->critic_b2, p->actor_w0, p->actor_b0, p->actor_w1, p->actor_b1,
+                        p->mean_w, p->mean_b, p->logstd};
+  for (const void* q : ptrs) if (!q) return fail(SOLORL_ERR_INVALID, "solorl_step_act: null policy parameter pointer");
+  const void* vec[] = {p->critic_w0, p->critic_w1, p->critic_w2, p->actor_w0, p->actor_w1, p->mean_w};
+  for (const void* q : vec) if (reinterpret_cast<uintptr_t>(q) & 15u) return fail(SOLORL_ERR_INVALID, "solorl_step_act: weight matrices must be 16-byte aligned (rows are read as float4)");
+  if (!h->reset_called) return fail(SOLORL_ERR_STATE, "env.reset() must be called before step");
+  if (!actions || !obs_out || !reward_out || !done_out) return fail(SOLORL_ERR_INVALID, "null array argument");
+  HIP_TRY(hipSetDevice(h->device));
+  Outputs o; memset(&o, 0, sizeof o);
+  o.obs = obs_out; o.rew = reward_out; o.done = done_out;
+  if (info) {
+    o.timeout = info->timeout; o.success = info->success; o.nan_reset = info->nan_reset; o.ep_len = info->episode_length;
+    o.ep_rew = info->episode_reward; o.goals = info->goals_reached; o.dr0 = info->dr_stand; o.dr1 = info->dr_joint_pose;
+    o.dr2 = info->dr_torque; o.dr3 = info->dr_balance; o.dr4 = info->dr_progress; o.ep_stats = info->ep_stats;
+    o.tau = info->applied_torque;
+  }
+  o.pol = PolicyTail{p->critic_w0, p->critic_b0, p->critic_w1, p->critic_b1, p->critic_w2, p->critic_b2, p->actor_w0, p->actor_b0, p->actor_w1, p->actor_b1,
+                     p->mean_w, p->mean_b, p->logstd, noise, value_out, action_out, logp_out};
   return dispatch_step(h, h->sf, h->si, h->N, actions, o, MODE_STEP, (hipStream_t)stream);
 }
 

@@ -113,7 +113,22 @@ class GraphedRollout:
         # the normal draws of all T steps and masks = 1 - done of all T steps are one launch each per rollout, not per step
         noise = torch.randn_like(st.actions) if fused else None
         done = torch.empty(self.T, st.num_agents, dtype=torch.uint8, device=st.device)
+        # ONE launch per rollout step where the engine supports it (solorl_step_act: each wavefront of the step kernel evaluates the policy
+        # on the observations it has just produced, in the time it would otherwise idle until the slowest wavefront ends); the first
+        # step's action still needs its own policy launch.  SOLORL_STEP_ACT=0 keeps the two-launch form (A/B runs).
+        import os
+        self.step_act = bool(fused and os.environ.get("SOLORL_STEP_ACT", "1") != "0" and hasattr(self.envs, "step_act_supported")
+                             and self.envs.step_act_supported(self._pp))
         for t in range(self.T):
+            if self.step_act:
+                if t == 0:
+                    policy_act(self._pp, st.obs[0], noise[0], st.value_preds[0], st.actions[0], st.action_log_probs[0])
+                if t + 1 < self.T:
+                    self.envs.step_act_inplace(st.actions[t], self._pp, noise[t + 1], st.value_preds[t + 1], st.actions[t + 1], st.action_log_probs[t + 1],
+                                               obs_out=st.obs[t + 1], rew_out=st.rewards[t], done_out=done[t])
+                else:
+                    self.envs.step_inplace(st.actions[t], obs_out=st.obs[t + 1], rew_out=st.rewards[t], done_out=done[t])
+                continue
             if fused:
                 policy_act(self._pp, st.obs[t], noise[t], st.value_preds[t], st.actions[t], st.action_log_probs[t])
             else:

@@ -184,6 +184,34 @@ class SoloVecEnv:
             _native.check(self.L.solorl_step(self._h, a, po, pr, C.c_void_p(d.data_ptr()), C.byref(self._info_c), self._stream()))
         return o, r, d, self._info
 
+    def step_act_supported(self, params):
+        """solorl_step_act (include/solorl.h): the engine's defaults (fp32, team mode, no sorting) and an observation size that is a
+        multiple of 4 floats (one history level) with the reference's hidden-64 MLP on it."""
+        import os
+        return (self.cfg.precision == 0 and os.environ.get("SOLORL_TEAM", "1") != "0" and os.environ.get("SOLORL_SORT", "0") == "0"
+                and self.obs_dim % 4 == 0 and params.obs_dim == self.obs_dim and params.act_dim == self.act_dim and params.hidden == 64)
+
+    def step_act_inplace(self, actions, params, noise, value_out, action_out, logp_out, obs_out=None, rew_out=None, done_out=None):
+        """step_inplace + Policy.act on the new observations in ONE launch (solorl_step_act): value_out [N] or [N,1], action_out [N,A] =
+        mean + exp(logstd) * noise (noise [N,A] or None), logp_out [N] or [N,1] -- e.g. the NEXT step's rollout-storage rows."""
+        a = self._raw("actions", actions, (self.nenvs, self.act_dim))
+        o = self._obs if obs_out is None else obs_out
+        r = self._rew if rew_out is None else rew_out
+        po = self._raw("obs_out", o, (self.nenvs, self.obs_dim))
+        pr = self._raw("rew_out", r, tuple(r.shape) if tuple(r.shape) in ((self.nenvs,), (self.nenvs, 1)) else (self.nenvs,))
+        d = self._done if done_out is None else done_out
+        if not (d.is_cuda and d.device == self.device and d.dtype == torch.uint8 and d.is_contiguous() and tuple(d.shape) == (self.nenvs,)):
+            raise AssertionError("done_out must be a contiguous uint8 [%d] tensor on %s" % (self.nenvs, self.device))
+        pv = self._raw("value_out", value_out, tuple(value_out.shape) if tuple(value_out.shape) in ((self.nenvs,), (self.nenvs, 1)) else (self.nenvs,))
+        pa = self._raw("action_out", action_out, (self.nenvs, self.act_dim))
+        pl = self._raw("logp_out", logp_out, tuple(logp_out.shape) if tuple(logp_out.shape) in ((self.nenvs,), (self.nenvs, 1)) else (self.nenvs,))
+        pn = C.c_void_p(0) if noise is None else self._raw("noise", noise, (self.nenvs, self.act_dim))
+        self._steps_issued += 1
+        with torch.cuda.device(self.device):
+            _native.check(self.L.solorl_step_act(self._h, a, po, pr, C.c_void_p(d.data_ptr()), C.byref(self._info_c), C.byref(params), pn, pv, pa, pl,
+                                                 self._stream()))
+        return o, r, d, self._info
+
     def get_observation(self):
         with torch.cuda.device(self.device):
             _native.check(self.L.solorl_get_observation(self._h, C.c_void_p(self._obs.data_ptr()), self._stream()))

@@ -80,11 +80,28 @@ def test_c_header_equals_the_json_table(robot, symbol):
         assert np.allclose(axis, j["axis"]) and np.allclose(jorigin, j["jorigin"], atol=1e-12) and np.allclose(com, j["com"], atol=1e-12)
         assert mass == pytest.approx(j["mass"]) and np.allclose(box, j["inertia_box"], rtol=1e-9) and np.allclose(urdf, j["inertia_urdf"])
     for h, j in zip(prims, m["prims"]):
-        link, axis, center, radius, friction, margin, halfw = h
+        link, axis, center, radius, friction, margin, halfw, nring, ring_y, ring_r = h
         assert halfw == pytest.approx(j["halfw"], rel=1e-9) and (halfw > 0) == (axis == 1)      # thick discs: knees and feet (K6, round 3)
+        assert nring == len(j["ring_y"]) == len(j["ring_r"]) and np.allclose(ring_y[:nring], j["ring_y"]) and np.allclose(ring_r[:nring], j["ring_r"])
+        if nring:           # the feet (round 4): ring 0 is the tread (radius, halfw), the others follow the chamfer inwards
+            assert link in m["foot_links"] and nring == 4 and (ring_y[0], ring_r[0]) == (halfw, radius)
+            assert all(ring_y[i] < ring_y[i + 1] and ring_r[i] > ring_r[i + 1] for i in range(3))
         assert link == j["link"] and np.allclose(center, j["center"], atol=1e-9) and radius == pytest.approx(j["radius"], abs=1e-7)
         assert friction == j["friction"] and margin == pytest.approx(j["margin"], rel=1e-6)
     assert [prims[p][0] for p in foot_prim] == m["foot_links"]        # the feet sensor reads the foot primitives
+
+
+def test_foot_profile_is_the_hulls(tmp_path):
+    """Hand-typed from the foot mesh (solo_foot: a wheel about the link's y axis, AABB 32 x 16.5 x 32 mm): tread of
+    radius 16 mm and half-width 2 mm, chamfered to a face of radius 11.7 mm at +-8.25 mm.  The profile rings reproduce the hull's support
+    function; round 3's full-radius thick disc overshot it by 1.1 / 2.1 / 2.8 mm at tilts of 10 / 20 / 45 degrees."""
+    for robot in ("solo8", "solo12"):
+        p = load_json(robot)["prims"][13]
+        ry, rr = np.array(p["ring_y"]), np.array(p["ring_r"])
+        assert (ry[0], rr[0]) == pytest.approx((0.002, 0.016), abs=1e-6) and (ry[-1], rr[-1]) == pytest.approx((0.00825, 0.01167), abs=2e-5)
+        for tilt, want in ((0, 16.0), (10, 16.10), (20, 15.77), (45, 14.37), (80, 10.15)):      # hull support heights (mm) measured from the mesh
+            t = np.radians(tilt)
+            assert 1e3 * (rr * np.cos(t) + ry * np.sin(t)).max() == pytest.approx(want, abs=0.06)
 
 
 def test_box_inertia_rule_k2():

@@ -165,14 +165,14 @@ def test_pointgoal_timeout_is_a_failure(gpu_device):
 def test_walk_torque_parity_input_divergence_horizon(gpu_device):
     """SURVEY.md 8(d) parity run verbatim on the HIP engine (see tests/test_host_harness.py for the regime: the robot
     is on the ground after 20 steps and the fp64 oracle itself, perturbed by 1e-12 rad, leaves the 1e-3 rad band after
-    `oracle_self_horizon` = 75 steps with round 4's friction cone -- 20 with round 3's pyramid, 61 with round 2's model: one e-fold every ~4 steps).  Divergence horizon = first control step with max |dq| > 1e-3 rad.
+    `oracle_self_horizon` = 106 steps with round 4's model (friction cone, hull-profile feet) -- 20 with round 3's, 61 with round 2's: one e-fold every ~5 steps).  Divergence horizon = first control step with max |dq| > 1e-3 rad.
     Actions cross the boundary as float32 (agents/ppo/envs.py:190-192 in the reference as well), so the engines are
     compared with the oracle driven by the SAME float32-rounded actions; that rounding alone (3e-8 relative on the
     torques) moves the oracle off its own float64-action fixture within a couple of dozen steps."""
     from oracle.oracle_py import Oracle
     g = np.load(os.path.join(GOLDEN, "walk_torque_traj.npz"))
     self_h = int(g["oracle_self_horizon"])
-    T = 130
+    T = 150
     acts32 = np.stack([walk_action(t).astype(np.float32) for t in range(T)])
     o64 = Oracle(walk_cfg(), 1, seed=1); o64.reset()
     o32 = Oracle(walk_cfg(), 1, seed=1); o32.reset()
@@ -196,8 +196,8 @@ def test_walk_torque_parity_input_divergence_horizon(gpu_device):
         assert max(dq[:10]) < (1e-9 if name == "f64" else 5e-4)
     print("divergence horizons (control steps): oracle self (1e-12 perturbation) %d, oracle under float32 action rounding %d, "
           "engine fp64 %d, engine fp32 %d" % (self_h, h_round, hor["f64"], hor["f32"]))
-    assert hor["f64"] >= self_h - 20, hor  # as long as the oracle's own horizon (75), within the scatter of a chaotic run
-    assert hor["f32"] >= 18, hor           # the same growth rate from fp32 rounding instead of 1e-12: ~25 steps (g++ build of the kernel math: 25)
+    assert hor["f64"] >= self_h - 25, hor  # as long as the oracle's own horizon (106), within the scatter of a chaotic run
+    assert hor["f32"] >= 20, hor           # the same growth rate from fp32 rounding instead of 1e-12 (g++ build of the kernel math: 35 steps)
 
 
 # (the fp32-outlier census lives in tests/test_parity_gpu3.py: test_error_tail_* -- every resynced workload, strict)

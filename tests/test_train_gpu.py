@@ -422,3 +422,82 @@ def test_config1_shape_64_envs_stand_ppo_smoke(gpu_device, tmp_path):
     assert all(abs(h["value_loss"]) < 1e3 and 1.0 < h["entropy"] < 1.6 for h in hist)
     ck = torch.load(os.path.join(str(tmp_path), "solo.pt"), weights_only=False)
     assert set(ck.keys()) == {"update", "state_dict", "ob_rms"}
+
+
+@pytest.mark.parametrize("robot,task,O,A,N", [(1, 1, 76, 12, 256), (1, 2, 84, 12, 67), (0, 0, 60, 8, 5)])
+def test_step_act_equals_step_then_policy_act(gpu_device, robot, task, O, A, N):
+    """solorl_step_act = solorl_step + solorl_policy_act on the new observations, in one launch (each wavefront of the step kernel
+    evaluates the policy for its own four envs): identical observations / rewards / done flags, and value, action, log-prob equal to the
+    separate kernel's up to the order of the f32 sums.  Ragged batch sizes (idle teams), with noise and deterministic, closed loop (the
+    produced actions drive the next step) -- and the reference-generated policy vectors of tests/golden/ppo_golden_kernel.pt pin
+    solorl_policy_act itself (tests/test_reference_pinned_gpu.py)."""
+    from solorl_amd.config import default_config
+    from solorl_amd.ppo.fused import policy_act, policy_params
+    from solorl_amd.vec_env import SoloVecEnv
+    dev = torch.device("cuda:0")
+    cfg = default_config(robot, task); cfg.num_history_stack = 1
+    pol = _random_policy(dev, O, A, seed=3)
+    P = policy_params(pol)
+    ea, eb = SoloVecEnv(cfg, N, device=dev, seed=4), SoloVecEnv(cfg, N, device=dev, seed=4)
+    assert ea.obs_dim == O and ea.act_dim == A and eb.step_act_supported(P)
+    oa, ob = ea.reset(), eb.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    act = torch.rand(N, A, device=dev, generator=g) * 2 - 1
+    worst = dict(v=0.0, a=0.0, l=0.0)
+    for t in range(40):
+        noise = torch.randn(N, A, device=dev, generator=g) if t % 3 else None
+        o1, r1, d1, _ = ea.step_inplace(act)
+        v1, a1, l1 = torch.empty(N, 1, device=dev), torch.empty(N, A, device=dev), torch.empty(N, 1, device=dev)
+        policy_act(P, o1, noise, v1, a1, l1)
+        v2, a2, l2 = torch.full((N, 1), 7.0, device=dev), torch.full((N, A), 7.0, device=dev), torch.full((N, 1), 7.0, device=dev)
+        o2, r2, d2, _ = eb.step_act_inplace(act, P, noise, v2, a2, l2)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+        for k, x, y in (("v", v1, v2), ("a", a1, a2), ("l", l1, l2)):
+            worst[k] = max(worst[k], float(((x - y).abs() / (1.0 + y.abs())).max()))
+        act = a2.clone()                       # closed loop
+    assert worst["v"] < 5e-6 and worst["a"] < 5e-6 and worst["l"] < 2e-5, worst
+    ea.close(); eb.close()
+
+
+def test_graphed_rollout_with_step_act_replays_like_the_two_launch_form(gpu_device, monkeypatch):
+    """GraphedRollout on solorl_step_act (one launch per step, the default where supported) against the two-launch form
+    (SOLORL_STEP_ACT=0) from the same seeds: the first observation row and its value agree, and each storage is internally consistent --
+    stored values / log-probs are the policy's on the stored observations / actions, stored observations are the engine's for the stored
+    actions (the captured normal draws differ between two graphs, so rows are not compared across them)."""
+    import numpy as np
+    from solorl_amd.config import default_config, ROBOT_SOLO12, TASK_WALK
+    from solorl_amd.ppo import Policy, RolloutStorage
+    from solorl_amd.ppo.graphs import GraphedRollout
+    from solorl_amd.vec_env import SoloVecEnv
+    dev = torch.device("cuda:0")
+    N, T = 256, 12
+    cfg = default_config(ROBOT_SOLO12, TASK_WALK); cfg.num_history_stack = 1
+    torch.manual_seed(0)
+    pol = Policy((76,), type("Box", (), {"shape": (12,)})(), None, {"hidden_size": 64}).to(dev)
+    stores = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SOLORL_STEP_ACT", mode)
+        env = SoloVecEnv(cfg, N, device=dev, seed=3)
+        st = RolloutStorage(T, N, (76,), 12, dev)
+        st.obs[0].copy_(env.reset())
+        with torch.no_grad():
+            pol.act(st.obs[0])
+        roll = GraphedRollout(env, pol, st, T)
+        roll()
+        torch.cuda.synchronize()
+        assert roll.step_act == (mode == "1")
+        g = {k: getattr(st, k).clone() for k in ("obs", "actions", "action_log_probs", "value_preds", "rewards", "masks")}
+        stores[mode] = g
+        with torch.no_grad():
+            for t in range(T):
+                v, lp, _ = pol.evaluate_actions(g["obs"][t], g["actions"][t])
+                assert torch.allclose(v, g["value_preds"][t], atol=1e-5) and torch.allclose(lp, g["action_log_probs"][t], atol=1e-4), (mode, t)
+        env2 = SoloVecEnv(cfg, N, device=dev, seed=3)
+        assert torch.equal(env2.reset(), g["obs"][0])
+        for t in range(T):
+            o, r, d, _ = env2.step_inplace(g["actions"][t].contiguous())
+            assert torch.equal(o, g["obs"][t + 1]) and torch.equal(r.view(-1), g["rewards"][t].view(-1)) and torch.equal(1.0 - d.float(), g["masks"][t + 1].view(-1))
+        env.close(); env2.close()
+    assert torch.equal(stores["1"]["obs"][0], stores["0"]["obs"][0]) and torch.allclose(stores["1"]["value_preds"][0], stores["0"]["value_preds"][0], atol=1e-6)
+    assert set(np.unique(stores["1"]["masks"].cpu().numpy())) <= {0.0, 1.0}

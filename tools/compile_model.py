@@ -59,6 +59,30 @@ def vec(s):
     return [float(x) for x in s.split()]
 
 
+MAX_RINGS = 4
+
+
+def ring_profile(y, rho, tol=5e-5):
+    """Profile rings (y_i >= 0, r_i) of a body of revolution given its vertices' |axis coordinate| and distance from the axis: the
+    support function towards a unit direction with components (s, a) = (|perpendicular|, |axial|) is max_i (r_i s + y_i a).  Ring 0 is
+    the outermost one (largest radius: the tread); further rings are added where the support error is largest until it is < tol."""
+    P = np.unique(np.round(np.stack([y, rho], axis=1), 6), axis=0)
+    th = np.linspace(0.0, 0.5 * np.pi, 721)
+    S, A = np.cos(th), np.sin(th)
+    full = (P[:, 1:2] * S + P[:, 0:1] * A).max(axis=0)
+    r0 = P[:, 1].max()
+    first = P[np.abs(P[:, 1] - r0) < 1e-6]
+    sel = [first[np.argmax(first[:, 0])]]                 # the tread's edge: largest |y| at the largest radius
+    while len(sel) < MAX_RINGS:
+        cur = np.max([p[1] * S + p[0] * A for p in sel], axis=0)
+        k = int(np.argmax(full - cur))
+        if full[k] - cur[k] < tol:
+            break
+        sel.append(P[np.argmax(P[:, 1] * S[k] + P[:, 0] * A[k])])
+    sel = [sel[0]] + sorted(sel[1:], key=lambda p: p[0])
+    return [round(float(p[0]), 6) for p in sel], [round(float(p[1]), 6) for p in sel]
+
+
 def compile_robot(desc_dir, urdf_name):
     root = ET.parse(os.path.join(desc_dir, "robots", urdf_name)).getroot()
     links_xml = {l.get("name"): l for l in root.findall("link")}
@@ -142,9 +166,16 @@ def compile_robot(desc_dir, urdf_name):
         # thickness below the disc's plane -- the zero-thickness discs of rounds 1-2 let lying legs sink 8-19 mm deeper than their hulls
         prims.append(dict(link=up, kind="disc", center=[0.0, float(yc), float(kfe[2])], axis=1, radius=r_knee,
                           halfw=float(0.5 * (ys.max() - ys.min()))))
+        # Foot (round 4, K6): the foot hull is a body of revolution about the link's y axis -- a wheel with a 4 mm wide tread of radius
+        # 16 mm chamfered down to 11.7 mm at its faces (+-8.25 mm) -- and its support function is that of its PROFILE, the rings
+        # (|y - yc|, rho).  Rings are picked greedily from the profile's convex hull until the support error is < 0.05 mm (<= 4).  radius /
+        # halfw describe ring 0, the tread.  (Round 3 took the full 16 mm radius out to the faces: a foot tilted by 10-45 degrees reached
+        # 1-3 mm too far and its contact point sat 8 mm off centre from a tilt of 6 degrees on, where the hull's stays on the tread up to
+        # 32 degrees -- measured with a trained walking policy: tests/test_parity_gpu3.py)
         hf = hulls[leg + "_FOOT"]
-        prims.append(dict(link=foot, kind="disc", center=[0.0, float(0.5 * (hf[:, 1].min() + hf[:, 1].max())), 0.0], axis=1,
-                          radius=float(np.hypot(hf[:, 0], hf[:, 2]).max()), halfw=float(0.5 * (hf[:, 1].max() - hf[:, 1].min()))))
+        yc = float(0.5 * (hf[:, 1].min() + hf[:, 1].max()))
+        ring_y, ring_r = ring_profile(np.abs(hf[:, 1] - yc), np.hypot(hf[:, 0], hf[:, 2]))
+        prims.append(dict(link=foot, kind="disc", center=[0.0, yc, 0.0], axis=1, radius=ring_r[0], halfw=ring_y[0], ring_y=ring_y, ring_r=ring_r))
     # Solo12 shoulder housings (K6, measured in tests/test_oracle_k6.py: -3 % terminations without them): one disc about the
     # link's x axis (= the HAA axis direction).  The hull's support function in the directions perpendicular to x,
     # h(theta) = max_v (v_y cos theta + v_z sin theta), is fitted by a circle yc cos + zc sin + r in the least-squares
@@ -165,6 +196,7 @@ def compile_robot(desc_dir, urdf_name):
         prims.append(dict(link=index[name], kind="disc", center=[clean(xw), clean(yc), clean(zc)], axis=0, radius=clean(r)))
     for p in prims:
         p.setdefault("halfw", 0.0)
+        p.setdefault("ring_y", []); p.setdefault("ring_r", [])
         p["friction"] = links[p["link"]]["friction"] * 1.0   # x plane.urdf lateral friction 1.0 [K6]
         p["margin"] = links[p["link"]]["margin"]
 
@@ -203,6 +235,10 @@ def emit_header(models, path):
     o.append("typedef struct solorl_prim_data {")
     o.append("  int link; int axis; /* -1 point, 0/1/2 disc axis */ double center[3]; double radius;")
     o.append("  double friction; double margin; double halfw; /* half-thickness of a disc along its axis */")
+    o.append("  /* nring > 1: a body of revolution about the disc axis given by its profile rings (ring_y[i] >= 0 from the centre plane, ring_r[i]);")
+    o.append("   * support point towards a direction with |perpendicular| s and |axial| a components: the ring maximising ring_r s + ring_y a.  Ring 0")
+    o.append("   * (radius, halfw) is the tread. */")
+    o.append("  int nring; double ring_y[4]; double ring_r[4];")
     o.append("} solorl_prim_data;")
     o.append("typedef struct solorl_model_data {")
     o.append("  const char* name; int nlinks; int ndof; int nprims; int foot_prim[4];")
@@ -223,8 +259,10 @@ def emit_header(models, path):
         o.append("  },")
         o.append("  {")
         for p in m["prims"]:
-            o.append("    {%d, %d, %s, %.17g, %.17g, %.17g, %.17g}," % (
-                p["link"], p["axis"], c_array(p["center"]), p["radius"], p["friction"], p["margin"], p["halfw"]))
+            ry = list(p["ring_y"]) + [0.0] * (4 - len(p["ring_y"])); rr = list(p["ring_r"]) + [0.0] * (4 - len(p["ring_r"]))
+            o.append("    {%d, %d, %s, %.17g, %.17g, %.17g, %.17g, %d, %s, %s}," % (
+                p["link"], p["axis"], c_array(p["center"]), p["radius"], p["friction"], p["margin"], p["halfw"], len(p["ring_y"]),
+                c_array(ry), c_array(rr)))
         o.append("  }")
         o.append("};")
     o.append("#endif")

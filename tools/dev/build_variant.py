@@ -1,4 +1,5 @@
-"""Build an A/B variant of the engine into ab_libs/<name>.so (git-ignored, ships with gpurun; select with SOLORL_LIB).
+"""Build an A/B variant of the WHOLE engine (one translation unit per source file) into ab_libs/<name>.so (git-ignored AND listed in .gpurunignore:
+take it out of that file for the call that runs the A/B; select with SOLORL_LIB).
 usage: build_variant.py NAME [-DDEFINE ...]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
