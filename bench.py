@@ -34,6 +34,7 @@ import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -166,7 +167,6 @@ class LineGuard:
     is waited for.  Exit code then: 0, or EXIT_WATCHDOG with --strict (the caller decides whether a partial line is acceptable)."""
 
     def __init__(self, rank, timeout_s, strict, build_line, ppo_requested, exit_fn=os._exit):
-        import threading
         self.rank, self.timeout_s, self.strict, self.build_line, self.exit_fn = rank, timeout_s, strict, build_line, exit_fn
         self.state = {"f64": None, "ppo": {"error": "not run"} if ppo_requested else None, "cpu": None, "printed": False}
         self.timer = threading.Timer(timeout_s, self.on_timeout)
