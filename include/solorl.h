@@ -74,7 +74,7 @@ typedef struct solorl_config {
   int32_t control;          /* SOLORL_CONTROL_* (config 'control', baseEnv.py:10; pd = pd/fpd/fixed_pd) */
   int32_t frame_skip;       /* config 'frame_skip' (default 4) */
   int32_t episode_length;   /* config 'episode_length' (baseEnv.py:164) */
-  int32_t num_history_stack;/* config 'num_history_stack' (0..2 supported) */
+  int32_t num_history_stack;/* config 'num_history_stack' (solo.py:48 deque(maxlen=h)): 0..4 (SOLORL_STATE_MAX_HISTORY) */
   int32_t hold_torque;      /* 0: torque acts on sub-step 1 only (Bullet clears it, K8); 1: held */
   int32_t use_urdf_inertia; /* 0: Bullet default box inertia from collision AABB (K2); 1: URDF tensor */
   int32_t solver_iterations;/* PGS iterations (PyBullet default 50, K7) */
@@ -162,11 +162,12 @@ typedef struct solorl_info_soa {
 #define SOLORL_STATE_MAX_DOF 12
 #define SOLORL_STATE_MAX_PRIMS 24
 #define SOLORL_STATE_MAX_OBS 42
+#define SOLORL_STATE_MAX_HISTORY 4
 typedef struct solorl_env_state {
   double pos[3], quat[4] /* x y z w */, lin_vel[3], ang_vel[3];
   double q[SOLORL_STATE_MAX_DOF], qd[SOLORL_STATE_MAX_DOF], tau[SOLORL_STATE_MAX_DOF];
   double lambda_prev[SOLORL_STATE_MAX_PRIMS];  /* warm-start normal impulses per collision primitive */
-  double hist[2][SOLORL_STATE_MAX_OBS];        /* state_history, [0] = newest */
+  double hist[SOLORL_STATE_MAX_HISTORY][SOLORL_STATE_MAX_OBS];   /* state_history, [0] = newest */
   double goal[2], potential, progress, goals_reached, env_goals_reached;
   double dr[5];                                /* stand, joint_pose, torque, balance, progress */
   double treadmill_y;                          /* centre line of the treadmill strip (+-treadmill_offset; 0 if unused) */

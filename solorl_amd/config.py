@@ -19,7 +19,7 @@ ABI_VERSION = 4            # SOLORL_ABI_VERSION (include/solorl.h)
 TASKS = {"stand": TASK_STAND, "walk": TASK_WALK, "pointgoal": TASK_POINTGOAL}
 CONTROLS = {"torque": CONTROL_TORQUE, "pd": CONTROL_PD, "fpd": CONTROL_PD, "fixed_pd": CONTROL_PD}
 
-MAX_DOF, MAX_PRIMS, MAX_OBS = 12, 24, 42
+MAX_DOF, MAX_PRIMS, MAX_OBS, MAX_HISTORY = 12, 24, 42, 4
 
 
 class SoloConfig(C.Structure):
@@ -62,7 +62,7 @@ class EnvState(C.Structure):
         ("pos", C.c_double * 3), ("quat", C.c_double * 4), ("lin_vel", C.c_double * 3),
         ("ang_vel", C.c_double * 3), ("q", C.c_double * MAX_DOF), ("qd", C.c_double * MAX_DOF),
         ("tau", C.c_double * MAX_DOF), ("lambda_prev", C.c_double * MAX_PRIMS),
-        ("hist", (C.c_double * MAX_OBS) * 2), ("goal", C.c_double * 2), ("potential", C.c_double),
+        ("hist", (C.c_double * MAX_OBS) * MAX_HISTORY), ("goal", C.c_double * 2), ("potential", C.c_double),
         ("progress", C.c_double), ("goals_reached", C.c_double), ("env_goals_reached", C.c_double),
         ("dr", C.c_double * 5), ("treadmill_y", C.c_double), ("timestep", C.c_int32), ("need_reset", C.c_int32),
         ("contact_mask", C.c_int32), ("rng_counter", C.c_int32),
@@ -140,8 +140,8 @@ def config_from_dict(d, **overrides):
     c.episode_length = int(d["episode_length"])
     c.num_history_stack = int(d.get("num_history_stack", 0))
     c.use_treadmill = 1 if d.get("use_treadmill", False) else 0        # baseEnv.py:13, simulation.py:9
-    if not 0 <= c.num_history_stack <= 2:
-        raise ValueError("num_history_stack must be 0..2")
+    if not 0 <= c.num_history_stack <= MAX_HISTORY:
+        raise ValueError("num_history_stack must be 0..%d" % MAX_HISTORY)
     gains = d.get("gains", None)
     if c.control == CONTROL_PD:
         if gains is None:

@@ -70,7 +70,7 @@ Layout make_layout(int n, int D, int H) {
   // every block starts on a multiple of 4 fields = a 64-B sector of the group (SX), and NF is one, so groups are sector-aligned
   auto align4 = [&]() { o = (o + 3) & ~3; };
   L.pos = o; o += 3; L.quat = o; o += 4; L.v = o; o += 3; L.w = o; o += 3;
-  L.q = o; o += n; L.qd = o; o += n; align4(); L.lam = o; o += NPRIM; align4(); L.hist = o; o += 2 * HSTRIDE; align4();
+  L.q = o; o += n; L.qd = o; o += n; align4(); L.lam = o; o += NPRIM; align4(); L.hist = o; o += (H > 2 ? H : 2) * HSTRIDE; align4();      // (levels 0 and 1 always have their place; deeper ones only when asked for)
   L.goal = o; o += 2; L.pot = o++; L.prog = o++; L.goals = o++; L.egoals = o++; L.dr = o; o += 5; L.xyprev = o; o += 2; L.tmy = o++;
   align4();
   L.NF = o;
@@ -268,6 +268,7 @@ SD void write_obs(const Env<T, Robot<ROBOT>::NQ>& E, const T* sf, const Layout& 
 #pragma unroll
       for (int h = 0; h < 2; h++)
         if (h < L.H) o[(h + 1) * L.D + d] = (float)(cs[d] - hv[h][d]);
+      for (int h = 2; h < L.H; h++) o[(h + 1) * L.D + d] = (float)(cs[d] - sf[SX(L.hist + h * HSTRIDE + d, e, L.NF)]);    // (deeper levels: straight from HBM)
     }
 }
 
@@ -310,12 +311,14 @@ SD void step_body(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
   if (L.H > 0) {
     T cs[DMAX], h0[DMAX];
     current_state<T, ROBOT>(E, P.task, cs);
+    for (int lv = L.H - 1; lv >= 2; lv--)              // levels beyond the second (num_history_stack 3, 4) shift in HBM, oldest first
+      for (int d = 0; d < L.D; d++) sf[SX(L.hist + lv * HSTRIDE + d, e, L.NF)] = sf[SX(L.hist + (lv - 1) * HSTRIDE + d, e, L.NF)];
 #pragma unroll
-    for (int d = 0; d < DMAX; d++) h0[d] = (L.H == 2 && d < L.D) ? sf[SX(L.hist + d, e, L.NF)] : T(0);   // loads first (see write_obs)
+    for (int d = 0; d < DMAX; d++) h0[d] = (L.H >= 2 && d < L.D) ? sf[SX(L.hist + d, e, L.NF)] : T(0);   // loads first (see write_obs)
 #pragma unroll
     for (int d = 0; d < DMAX; d++)
       if (d < L.D) {
-        if (L.H == 2) sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = h0[d];
+        if (L.H >= 2) sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = h0[d];
         sf[SX(L.hist + d, e, L.NF)] = cs[d];
       }
   }
@@ -652,12 +655,14 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const int d = t + 16 * k;
       if (d < L.D) {
         const T c = csk[k];
-        if (L.H == 2) { hk1[k] = sf[SX(L.hist + d, e, L.NF)]; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = hk1[k]; }
+        for (int lv = L.H - 1; lv >= 2; lv--)          // levels beyond the second (num_history_stack 3, 4) shift in HBM, oldest first; same lane, same elements
+          sf[SX(L.hist + lv * HSTRIDE + d, e, L.NF)] = sf[SX(L.hist + (lv - 1) * HSTRIDE + d, e, L.NF)];
+        if (L.H >= 2) { hk1[k] = sf[SX(L.hist + d, e, L.NF)]; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = hk1[k]; }
         sf[SX(L.hist + d, e, L.NF)] = c;
         hk0[k] = c;
       } else if (d < ((L.D + 3) & ~3)) {               // (pad: the level's last sector is written whole)
         sf[SX(L.hist + d, e, L.NF)] = T(0);
-        if (L.H == 2) sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = T(0);
+        for (int lv = 1; lv < L.H; lv++) sf[SX(L.hist + lv * HSTRIDE + d, e, L.NF)] = T(0);
       }
     }
   }
@@ -780,7 +785,7 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
       const int d = t + 16 * kk;
       if (d < L.D) {
         if (L.H >= 1) hk0[kk] = snf[SX(L.hist + d, k, L.NF)];
-        if (L.H == 2) hk1[kk] = snf[SX(L.hist + HSTRIDE + d, k, L.NF)];
+        if (L.H >= 2) hk1[kk] = snf[SX(L.hist + HSTRIDE + d, k, L.NF)];
       }
     }
     TEAM_SYNC();
@@ -792,7 +797,8 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
         if (d == L.D - 2 || d == L.D - 1) {
           const T gv = (d == L.D - 2 ? g0 : g1) * T(0.5);
           if (L.H >= 1) { hk0[kk] = gv; sf[SX(L.hist + d, e, L.NF)] = gv; }
-          if (L.H == 2) { hk1[kk] = gv; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = gv; }
+          if (L.H >= 2) { hk1[kk] = gv; sf[SX(L.hist + HSTRIDE + d, e, L.NF)] = gv; }
+          for (int lv = 2; lv < L.H; lv++) sf[SX(L.hist + lv * HSTRIDE + d, e, L.NF)] = gv;
         }
       }
     }
@@ -828,11 +834,20 @@ SD void step_team(T* __restrict__ sf, int* __restrict__ si, const T* __restrict_
           const T c = cso[k];
           o[d] = (float)c;
           if (L.H >= 1) o[L.D + d] = (float)(c - hk0[k]);
-          if (L.H == 2) o[2 * L.D + d] = (float)(c - hk1[k]);
-          if (with_policy) {
+          if (L.H >= 2) o[2 * L.D + d] = (float)(c - hk1[k]);
+          for (int lv = 2; lv < L.H; lv++) {
+            // levels beyond the second live in HBM only.  An env that was just reset reads its snapshot (the team's copy above was
+            // written by OTHER lanes) with the new goal patched in; any other env reads what this same lane shifted at the history push
+            T hv;
+            if (done) {
+              hv = snf[SX(L.hist + lv * HSTRIDE + d, (idx_t)C.irec[IR_SNAP], L.NF)];
+              if (P.task == SOLORL_TASK_POINTGOAL && d >= L.D - 2) hv = C.erec[ER_GOAL + (d - (L.D - 2))] * T(0.5);
+            } else hv = sf[SX(L.hist + lv * HSTRIDE + d, e, L.NF)];
+            o[(lv + 1) * L.D + d] = (float)(c - hv);
+          }
+          if (with_policy) {               // (only for obs sizes the policy kernels know: at most one history level)
             ol[d] = (float)c;
             if (L.H >= 1) ol[L.D + d] = (float)(c - hk0[k]);
-            if (L.H == 2) ol[2 * L.D + d] = (float)(c - hk1[k]);
           }
         }
       }
@@ -1254,7 +1269,7 @@ int check_cfg(const solorl_config* c) {
   if (c->task < 0 || c->task > 2) return fail(SOLORL_ERR_INVALID, "task must be stand/walk/pointgoal");
   if (c->control != SOLORL_CONTROL_TORQUE && c->control != SOLORL_CONTROL_PD) return fail(SOLORL_ERR_INVALID, "control must be torque or pd");
   if (c->frame_skip < 1 || c->frame_skip > 64) return fail(SOLORL_ERR_INVALID, "frame_skip out of range");
-  if (c->num_history_stack < 0 || c->num_history_stack > 2) return fail(SOLORL_ERR_INVALID, "num_history_stack must be 0..2");
+  if (c->num_history_stack < 0 || c->num_history_stack > SOLORL_STATE_MAX_HISTORY) return fail(SOLORL_ERR_INVALID, "num_history_stack must be 0..4");
   if (c->episode_length < 1) return fail(SOLORL_ERR_INVALID, "episode_length must be >= 1");
   if (c->settle_min < 0 || c->settle_max < c->settle_min || c->settle_max > 64) return fail(SOLORL_ERR_INVALID, "bad settle range");
   if (c->settle_min < c->num_history_stack) return fail(SOLORL_ERR_INVALID, "settle_min must be >= num_history_stack");
@@ -1581,7 +1596,8 @@ int solorl_get_state(solorl_env* h, int i, solorl_env_state* out) {
   for (int k = 0; k < 4; k++) out->quat[k] = f[L.quat + k];
   for (int j = 0; j < h->n; j++) { out->q[j] = f[L.q + j]; out->qd[j] = f[L.qd + j]; }
   for (int p = 0; p < NPRIM; p++) out->lambda_prev[p] = f[L.lam + p];
-  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) out->hist[hh][d] = f[L.hist + hh * HSTRIDE + d];
+  for (int hh = 0; hh < SOLORL_STATE_MAX_HISTORY; hh++)
+    for (int d = 0; d < DMAX; d++) out->hist[hh][d] = hh < (L.H > 2 ? L.H : 2) ? f[L.hist + hh * HSTRIDE + d] : 0.0;
   out->goal[0] = f[L.goal]; out->goal[1] = f[L.goal + 1]; out->potential = f[L.pot]; out->progress = f[L.prog];
   out->goals_reached = f[L.goals]; out->env_goals_reached = f[L.egoals];
   for (int k = 0; k < 5; k++) out->dr[k] = f[L.dr + k];
@@ -1603,7 +1619,7 @@ int solorl_set_state(solorl_env* h, int i, const solorl_env_state* in) {
   for (int k = 0; k < 4; k++) f[L.quat + k] = in->quat[k];
   for (int j = 0; j < h->n; j++) { f[L.q + j] = in->q[j]; f[L.qd + j] = in->qd[j]; }
   for (int p = 0; p < NPRIM; p++) f[L.lam + p] = in->lambda_prev[p];
-  for (int hh = 0; hh < 2; hh++) for (int d = 0; d < DMAX; d++) f[L.hist + hh * HSTRIDE + d] = in->hist[hh][d];
+  for (int hh = 0; hh < (L.H > 2 ? L.H : 2); hh++) for (int d = 0; d < DMAX; d++) f[L.hist + hh * HSTRIDE + d] = in->hist[hh][d];
   f[L.goal] = in->goal[0]; f[L.goal + 1] = in->goal[1]; f[L.pot] = in->potential; f[L.prog] = in->progress;
   f[L.goals] = in->goals_reached; f[L.egoals] = in->env_goals_reached;
   for (int k = 0; k < 5; k++) f[L.dr + k] = in->dr[k];

@@ -9,7 +9,7 @@ def lib():
         so = os.path.join(HERE, "libharness.so")
         srcs = [os.path.join(HERE, "host_harness.cpp"), os.path.join(HERE, "host_shim.hpp"),
                 os.path.join(HERE, "../../solorl_amd/csrc/dynamics.hpp"), os.path.join(HERE, "../../solorl_amd/csrc/spatial.hpp"),
-                os.path.join(HERE, "../../include/solorl_model_data.h")]
+                os.path.join(HERE, "../../include/solorl_model_data.h"), os.path.join(HERE, "../../include/solorl.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + HERE, "-o", so, srcs[0]])
         _L = C.CDLL(so)

@@ -35,7 +35,7 @@ def test_default_config_matches_python_mirror(lib):
             assert lib.solorl_default_config(C.byref(c), robot, task) == 0
             assert bytes(c) == bytes(default_config(robot, task))
     assert C.sizeof(SoloConfig) == 16 * 4 + 19 * 8        # 15 int32 (+ 4 bytes of padding before the doubles) + 19 doubles
-    assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 24 + 2 * 42 + 2 + 4 + 5 + 1) + 4 * 4
+    assert C.sizeof(EnvState) == 8 * (3 + 4 + 3 + 3 + 12 * 3 + 24 + 4 * 42 + 2 + 4 + 5 + 1) + 4 * 4       # hist[SOLORL_STATE_MAX_HISTORY = 4][42]
 
 
 def test_error_convention(lib):

@@ -56,6 +56,25 @@ def test_history_is_pre_step_state():
     assert np.allclose(np.array(o.get_state(0).hist[0])[:38], before)   # solo.py:262
 
 
+def test_history_stack_of_four_is_a_deque():
+    """solo.py:48,186-196,262: `state_history = deque(maxlen=h)`; the observation is [s, s - newest, ..., s - oldest].  h = 4 (the state
+    structure's maximum, SOLORL_STATE_MAX_HISTORY): after k steps level j holds the pre-step state of step k - j."""
+    c = mk(ROBOT_SOLO12, TASK_WALK, num_history_stack=4, settle_min=5, settle_max=5, disable_termination=1)
+    o = Oracle(c, 1); ob = o.reset()[0]
+    assert ob.shape == (38 * 5,)
+    pre = []
+    rng = np.random.default_rng(0)
+    for k in range(6):
+        pre.append(o.get_observation()[0][:38].copy())
+        ob = o.step(0.3 * rng.uniform(-1, 1, (1, 12)))[0][0]
+        s = o.get_state(0)
+        for j in range(min(4, k + 1)):
+            assert np.allclose(np.array(s.hist[j])[:38], pre[k - j]), (k, j)
+            d = ob[38 * (j + 1):38 * (j + 2)] - (ob[:38] - pre[k - j])
+            d[1:4] = 0                              # (euler entries wrap: (e % 2)/2)
+            assert np.abs(d).max() < 1e-12
+
+
 def test_reward_stand_walk_pointgoal():
     a = np.linspace(-1.5, 1.5, 12)[None]                                # raw, unclipped action
     for task in (TASK_STAND, TASK_WALK, TASK_POINTGOAL):

@@ -6,7 +6,8 @@
   * the error TAIL of every resynced workload explained or bounded: a sample above the north-star tolerance must be a state the fp64
     engine amplifies too (or a contact flipping at its threshold), quiet states are held to a maximum;
   * BASELINE config 2 verbatim at full size (configs/basic.yaml, task stand, 4096 envs);
-  * the friction PYRAMID and contact ERP 0.2 of rounds 1-3, now options, in team mode, lane mode and fp64.
+  * the friction PYRAMID and contact ERP 0.2 of rounds 1-3, now options, in team mode, lane mode and fp64;
+  * `num_history_stack` 3 and 4.
 """
 import os
 
@@ -342,3 +343,41 @@ def test_friction_model_and_contact_erp_options_vs_oracle(gpu_device, monkeypatc
     else:
         assert np.median(dq) < 1e-4 and np.percentile(dq, 90) < 1e-3, (np.median(dq), np.percentile(dq, 90))
     assert mism <= 0.02 * len(dq)
+
+
+# ------------------------------------------------------------------------------------------------ history depth beyond two levels
+@pytest.mark.parametrize("team", ["1", "0"])
+@pytest.mark.parametrize("robot,task,H", [(ROBOT_SOLO12, TASK_POINTGOAL, 3), (ROBOT_SOLO8, TASK_WALK, 4)])
+def test_history_depth_beyond_two_levels(gpu_device, monkeypatch, team, robot, task, H):
+    """`num_history_stack` 3 and 4 (the reference takes any depth: solo.py:48 `deque(maxlen=num_history_stack)`; VERDICT r03 Missing #5).
+    Levels 0 and 1 ride in registers, deeper ones shift in HBM.  Unsynchronised comparison of the WHOLE observation -- [s, s - h0, ... ,
+    s - h(H-1)] -- with the oracle over 12 steps from reset (resynchronised state: the history is part of it), including auto-resets
+    (short episodes) and, for pointgoal, the new goal patched into every level."""
+    monkeypatch.setenv("SOLORL_TEAM", team)
+    c = cfg_for(robot, task, num_history_stack=H, episode_length=7)
+    N = 64
+    env, orc = make(c, N, seed=8)
+    og = env.reset().cpu().numpy().astype(np.float64); oo = orc.reset()
+    assert og.shape == oo.shape == (N, c.state_dim * (1 + H))
+    assert obs_diff(og, oo, c.state_dim).max() < 2e-3
+    rng = np.random.default_rng(1)
+    n = env.act_dim
+    worst = 0.0
+    for t in range(16):
+        for i in range(N):
+            orc.set_state(i, env.get_state(i))
+        a = (0.3 * rng.uniform(-1, 1, size=(N, n))).astype(np.float32)
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        oobs, orew, odone, _ = orc.step(a.astype(np.float64))
+        done = done.cpu().numpy()
+        assert np.array_equal(done != 0, odone != 0)
+        d = obs_diff(obs.cpu().numpy(), oobs, c.state_dim)
+        # the deltas of the DEEPER levels are differences of states several steps apart: fp32 rounding of each, nothing more
+        worst = max(worst, float(np.median(d.max(axis=1))))
+        assert np.percentile(d.max(axis=1), 90) < 2e-3, (t, np.percentile(d.max(axis=1), 90))
+        if t in (6, 13):
+            assert done.sum() == N           # timeout at episode_length = 7: every env resets, history refilled from the snapshot
+        sg, so = env.get_state(3), orc.get_state(3)
+        for lv in range(H):
+            assert np.abs(np.array(sg.hist[lv])[:c.state_dim] - np.array(so.hist[lv])[:c.state_dim]).max() < 2e-3, (t, lv)
+    assert worst < 1e-4, worst
