@@ -253,32 +253,42 @@ def ppo_leg(env, dev, world, T, epochs):
            "allreduce_in_graph": bool(getattr(agent, "allreduce_in_graph", False)) if world > 1 else None,
            "ppo_epoch": epochs, "mini_batches_per_epoch": (T * N) // mb, "mini_batch": mb, "optimizer_steps": epochs * ((T * N) // mb),
            "note": "policy act (solorl_policy_act) + env.step writing into the rollout storage per step, then GAE + PPO epochs (solorl_ppo_grad_stage1/2 + clip + Adam per mini-batch); rollout and mini-batch step replayed from HIP graphs"}
-    if world > 1:                   # the collective of the data-parallel PPO step, timed on its own -- on SCRATCH tensors of the
-        from solorl_amd.ppo import dist as D      # bucket's size (zeros: 50 summed all-reduces of live gradients would overflow)
-        from solorl_amd.ppo.graphs import probe_captured_allreduce
-        reps = 50
-
-        def eager_us(numel):
-            x = torch.zeros(numel, device=dev)
-            dist.all_reduce(x)
-            sync(); t0 = time.perf_counter()
-            for _ in range(reps):
-                dist.all_reduce(x, op=dist.ReduceOp.SUM)
-            sync()
-            return 1e6 * (time.perf_counter() - t0) / reps
-
-        nb = agent.bucket.flat.numel()
-        out["grad_allreduce"] = {"bytes": nb * 4, "us_per_call": eager_us(nb), "us_per_call_8_bytes": eager_us(2),
-                                 "calls_per_update": out["optimizer_steps"], "backend": dist.get_backend(), "rccl_env": D.rccl_env(),
-                                 "note": "eager all_reduce(sum) of a scratch tensor of the bucket's size; beside it the same call on 8 bytes: "
-                                         "equal latencies = the bucket is latency-bound, whatever algorithm RCCL's tuner picked"}
-        if dist.get_backend() == "nccl":          # one execution of a CAPTURED all-reduce of the real bucket size (opt-in for training)
-            try:
-                ok, sec = probe_captured_allreduce(dev, nb, replays=8, time_it=True)
-                out["grad_allreduce"]["captured_probe"] = {"ok": ok, "us_per_replay": None if sec is None else 1e6 * sec, "replays_checked": 8}
-            except Exception as ex:
-                out["grad_allreduce"]["captured_probe"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    out["bucket_numel"] = agent.bucket.flat.numel()
     return out
+
+
+def allreduce_leg(dev, world, numel, optimizer_steps, sync):
+    """The collective of the data-parallel PPO step, timed on its own -- on SCRATCH tensors of the bucket's size (zeros: 50 summed
+    all-reduces of live gradients would overflow).  Returns the eager part; `captured_allreduce_probe` is a separate call so that a
+    captured collective that hangs on first contact with real xGMI costs only its own entry, not the PPO leg's numbers."""
+    import torch
+    import torch.distributed as dist
+    from solorl_amd.ppo import dist as D
+    reps = 50
+
+    def eager_us(n):
+        x = torch.zeros(n, device=dev)
+        dist.all_reduce(x)
+        sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        sync()
+        return 1e6 * (time.perf_counter() - t0) / reps
+
+    return {"bytes": numel * 4, "us_per_call": eager_us(numel), "us_per_call_8_bytes": eager_us(2), "calls_per_update": optimizer_steps,
+            "backend": dist.get_backend(), "rccl_env": D.rccl_env(),
+            "note": "eager all_reduce(sum) of a scratch tensor of the bucket's size; beside it the same call on 8 bytes: "
+                    "equal latencies = the bucket is latency-bound, whatever algorithm RCCL's tuner picked"}
+
+
+def captured_allreduce_probe(dev, numel):
+    """One execution of a CAPTURED all-reduce of the real bucket size (opt-in for training: SOLORL_CAPTURE_ALLREDUCE=1), nccl only."""
+    from solorl_amd.ppo.graphs import probe_captured_allreduce
+    try:
+        ok, sec = probe_captured_allreduce(dev, numel, replays=8, time_it=True)
+        return {"ok": ok, "us_per_replay": None if sec is None else 1e6 * sec, "replays_checked": 8}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
 def main(argv=None):
@@ -508,6 +518,14 @@ def main(argv=None):
         if world > 1 and not all_ranks("error" not in (ppo or {})):   # and every rank that does return agrees on the outcome before
             ppo = ppo if (ppo and "error" in ppo) else {"error": "the PPO leg failed on another rank"}     # any further collective
     state["ppo"] = ppo
+    if world > 1 and ppo and "error" not in ppo:          # after the PPO leg's numbers are safe in `state` (a hang below costs only its own entry)
+        try:
+            ppo["grad_allreduce"] = allreduce_leg(dev, world, ppo["bucket_numel"], ppo["optimizer_steps"], barrier)
+            if dist.get_backend() == "nccl":
+                ppo["grad_allreduce"]["captured_probe"] = {"error": "did not finish (watchdog)"}
+                ppo["grad_allreduce"]["captured_probe"] = captured_allreduce_probe(dev, ppo["bucket_numel"])
+        except Exception as ex:
+            ppo["grad_allreduce"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         state["cpu"] = cpu_baseline(cfg)

@@ -506,6 +506,11 @@ SD float pol_tanh(float x) { const float e = __expf(2.0f * x); return 1.0f - 2.0
 typedef float nfloat4 __attribute__((ext_vector_type(4)));          // (native vector: HIP's float4 class cannot be read through an address-space pointer)
 typedef __attribute__((address_space(1))) const nfloat4 gfloat4;
 SD float pol_dot4(nfloat4 w, nfloat4 x, float acc) { return fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, acc)))); }
+// A lone wavefront has nothing to hide a load's latency behind, so the weight loads are issued in explicit BATCHES (POL_KB input chunks x 8
+// rows = 32 float4 per batch) with a compiler barrier behind them that also re-defines the loaded values -- left to itself the scheduler
+// kept ~8 loads in flight and waited for them one or two at a time (19 exposed L2 round trips in layer 1 alone: the tail took 29 us).
+constexpr int POL_KB = 4;
+#define POL_PIN4(x) asm volatile("" : "+v"(x))
 template <int A>
 SD void policy_tail_team(const PolicyTail& P, int O, int col, int t, idx_t env, bool valid) {
   float* const buf = reinterpret_cast<float*>(solo_smem + (unsigned)col * POL_ENV_BYTES);
@@ -519,15 +524,35 @@ SD void policy_tail_team(const PolicyTail& P, int O, int col, int t, idx_t env, 
     gfloat4* wa = (gfloat4*)(P.aw0 + (size_t)(4 * t) * O);
 #pragma unroll
     for (int u = 0; u < 4; u++) { c[u] = P.cb0[4 * t + u]; a[u] = P.ab0[4 * t + u]; }
-#pragma unroll 4                                   // (32 weight loads in flight per batch: a lone wavefront has nothing else to hide their latency)
-    for (int k = 0; k < O4; k++) {
-      const nfloat4 x = obs4[k];
+#pragma unroll 1
+    for (int k0 = 0; k0 < O4; k0 += POL_KB) {
+      nfloat4 wcb[POL_KB][4], wab[POL_KB][4], xb[POL_KB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wc[u * O4 + k], x, c[u]); a[u] = pol_dot4(wa[u * O4 + k], x, a[u]); }
+      for (int kk = 0; kk < POL_KB; kk++) {
+        const int k = k0 + kk < O4 ? k0 + kk : O4 - 1;          // (past the end: the last chunk again, not accumulated)
+        xb[kk] = obs4[k];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { wcb[kk][u] = wc[u * O4 + k]; wab[kk][u] = wa[u * O4 + k]; }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < POL_KB; kk++) {
+        POL_PIN4(xb[kk]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { POL_PIN4(wcb[kk][u]); POL_PIN4(wab[kk][u]); }
+      }
+#pragma unroll
+      for (int kk = 0; kk < POL_KB; kk++)
+        if (k0 + kk < O4) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wcb[kk][u], xb[kk], c[u]); a[u] = pol_dot4(wab[kk][u], xb[kk], a[u]); }
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) { h1[4 * t + u] = pol_tanh(c[u]); h1[64 + 4 * t + u] = pol_tanh(a[u]); }
   }
+  static_assert(A < 15, "the critic head sits on lane 15");
+  const bool head = t < A || t == 15;
   TEAM_SYNC();
   {   // layer 2
     gfloat4* wc = (gfloat4*)(P.cw1 + (size_t)(4 * t) * 64);
@@ -535,25 +560,47 @@ SD void policy_tail_team(const PolicyTail& P, int O, int col, int t, idx_t env, 
     const nfloat4* xc = reinterpret_cast<const nfloat4*>(h1); const nfloat4* xa = reinterpret_cast<const nfloat4*>(h1 + 64);
 #pragma unroll
     for (int u = 0; u < 4; u++) { c[u] = P.cb1[4 * t + u]; a[u] = P.ab1[4 * t + u]; }
-#pragma unroll 8
-    for (int k = 0; k < 16; k++) {
-      const nfloat4 x = xc[k], y = xa[k];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wc[u * 16 + k], x, c[u]); a[u] = pol_dot4(wa[u * 16 + k], y, a[u]); }
+    for (int k0 = 0; k0 < 16; k0 += POL_KB) {
+      nfloat4 wcb[POL_KB][4], wab[POL_KB][4], xcb[POL_KB], xab[POL_KB];
+#pragma unroll
+      for (int kk = 0; kk < POL_KB; kk++) {
+        xcb[kk] = xc[k0 + kk]; xab[kk] = xa[k0 + kk];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { wcb[kk][u] = wc[u * 16 + k0 + kk]; wab[kk][u] = wa[u * 16 + k0 + kk]; }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < POL_KB; kk++) {
+        POL_PIN4(xcb[kk]); POL_PIN4(xab[kk]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { POL_PIN4(wcb[kk][u]); POL_PIN4(wab[kk][u]); }
+      }
+#pragma unroll
+      for (int kk = 0; kk < POL_KB; kk++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wcb[kk][u], xcb[kk], c[u]); a[u] = pol_dot4(wab[kk][u], xab[kk], a[u]); }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) { h2[4 * t + u] = pol_tanh(c[u]); h2[64 + 4 * t + u] = pol_tanh(a[u]); }
   }
   TEAM_SYNC();
   // heads: lane t < A -> mean_t (and the action, its log-prob term), lane 15 -> value
-  static_assert(A < 15, "the critic head sits on lane 15");
   float out = 0.f;
-  if (t < A || t == 15) {
-    gfloat4* w = (gfloat4*)(t == 15 ? P.cw2 : P.mw + (size_t)t * 64);
-    const nfloat4* x = reinterpret_cast<const nfloat4*>(t == 15 ? h2 : h2 + 64);
-    out = t == 15 ? P.cb2[0] : P.mb[t];
+  {
+    gfloat4* wh = (gfloat4*)(t == 15 ? P.cw2 : P.mw + (size_t)(head ? t : 0) * 64);
+    nfloat4 whb[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) out = pol_dot4(w[k], x[k], out);
+    for (int k = 0; k < 16; k++) whb[k] = wh[k];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 16; k++) POL_PIN4(whb[k]);
+    const nfloat4* x = reinterpret_cast<const nfloat4*>(t == 15 ? h2 : h2 + 64);
+    float o0 = t == 15 ? P.cb2[0] : P.mb[head ? t : 0], o1 = 0.f;        // (two chains: the head is 64 dependent multiply-adds otherwise)
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) { o0 = pol_dot4(whb[k], x[k], o0); o1 = pol_dot4(whb[k + 1], x[k + 1], o1); }
+    out = head ? o0 + o1 : 0.f;
   }
   float lp = 0.f, act = out;
   if (t < A) {
