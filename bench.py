@@ -175,6 +175,15 @@ class LineGuard:
     def start(self):
         self.timer.start()
 
+    def rearm(self, timeout_s):
+        """A shorter fuse for the section that follows (the first captured RCCL all-reduce this project ever runs on two GPUs is the last
+        thing a multi-GPU run does: if it hangs, the line goes out after `timeout_s`, not after the legs' whole budget)."""
+        self.timer.cancel()
+        self.timeout_s = timeout_s
+        self.timer = threading.Timer(timeout_s, self.on_timeout)
+        self.timer.daemon = True
+        self.timer.start()
+
     def emit(self, extra_note=None):
         if self.state["printed"] or self.rank != 0:
             return
@@ -522,6 +531,7 @@ def main(argv=None):
         try:
             ppo["grad_allreduce"] = allreduce_leg(dev, world, ppo["bucket_numel"], ppo["optimizer_steps"], barrier)
             if dist.get_backend() == "nccl":
+                guard.rearm(60)
                 ppo["grad_allreduce"]["captured_probe"] = {"error": "did not finish (watchdog)"}
                 ppo["grad_allreduce"]["captured_probe"] = captured_allreduce_probe(dev, ppo["bucket_numel"])
         except Exception as ex:

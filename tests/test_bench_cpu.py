@@ -97,3 +97,15 @@ def test_rccl_filters_are_exported_before_the_communicator_exists(monkeypatch):
     assert D.pin_rccl_from_env() == {"NCCL_ALGO": "Tree", "NCCL_PROTO": "LL"}
     assert os.environ["NCCL_ALGO"] == "Tree"
     monkeypatch.delenv("NCCL_ALGO"); monkeypatch.delenv("NCCL_PROTO")
+
+
+def test_line_guard_rearm_shortens_the_fuse():
+    """The captured-all-reduce probe (the last thing a multi-GPU bench does) gets its own 60 s fuse: rearm() replaces the running timer."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import time
+    fired = []
+    g = bench.LineGuard(1, 3600, False, lambda st: {"metric": "m"}, False, exit_fn=fired.append)
+    g.start(); g.rearm(0.2)
+    time.sleep(0.6)
+    assert fired == [0] and g.timeout_s == 0.2

@@ -63,7 +63,9 @@ def test_trained_policy_statistics_engine_vs_oracle(gpu_device, name, cfg_file, 
     link -- which the engine's one-point primitives approximate) is held to the same success / length bounds for the
     stand and pointgoal policies.  For the WALKING gait it is not, and the test records that instead of hiding it: a gait trained on
     one-point contacts succeeds 0.9 here and 0.2-0.5 on the manifold model (measured round 4; feet alone account for it: their hull SHAPE
-    is exact since round 4, the persistent multi-point patch under each foot is what the engine does not have).  That is the open K6 item."""
+    is exact since round 4, the persistent multi-point patch under each foot is what the engine does not have).  How much of that is the
+    gait's own brittleness: on the primitives it was trained on, 400 solver sweeps instead of 50 alone take it from 0.89 to 0.17 (DESIGN.md
+    section 3 K6 iii).  That is the open K6 item."""
     from oracle.oracle_py import Oracle
     from solorl_amd.vec_env import SoloVecEnv
     d = load_yaml(os.path.join(ROOT, "configs", cfg_file)); d["task"] = task
