@@ -690,6 +690,19 @@ SNI void phase_leg(CH ch, const PhysParams<T> pp, const T* lam_prev, unsigned ns
 }
 
 #ifndef SOLO_HOST_SHIM
+#ifndef SOLO_LEG_QUAD
+#define SOLO_LEG_QUAD 1          // 0: one lane per leg (rounds 1-3); A/B builds
+#endif
+// value of sub-lane S of this lane's quad (lanes 4q .. 4q+3): one DPP move (two for a double)
+template <int S, typename T> SD T quad_bcast(T x) {
+  constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);           // quad_perm:[S,S,S,S]
+  if constexpr (sizeof(T) == 4) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), ctrl, 0xF, 0xF, true));
+  else {
+    const long long v = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(v & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp((int)(v >> 32), ctrl, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+}
 // ---------------------------------------------------------------- phase 2, team mode: the four legs in parallel
 // Lane L (0..3) of a team processes leg L.  The legs are mirror images, so the code is the same and
 // only constants differ: they are picked per lane from the four legs' compile-time values
@@ -714,8 +727,13 @@ template <typename T> SD LegSign<T> leg_sign(int L) {
     else if constexpr (b_ == -a_ && c_ == -a_ && d_ == a_) return T(a_) * (g).sxy; \
     else return T(a_) + T(b_ - a_) * (g).m1 + T(c_ - a_) * (g).m2 + T(d_ - a_) * (g).m3; }())
 template <typename T, int ROBOT, typename LDS, typename CH, bool UI>
-SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L) {   // (by reference:
+SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, unsigned nstride, const LDS lds, int L, int sub) {   // (pp by reference:
                                                                      // ten more live argument registers made this phase spill 101 VGPRs)
+  // Round 4 (SOLO_LEG_QUAD): leg L runs on the FOUR lanes of quad L (sub = lane & 3) instead of one.  Kinematics, link terms, the
+  // articulated-body pass and qdd0 are computed redundantly by the four (SIMT: the same instructions, no extra time); what used to be
+  // loops over independent pieces is split across them -- the NJ columns of the leg's response (G_j, Minv[:, j]: column `sub`, then
+  // exchanged with quad_perm broadcasts) and the three rows of every touching primitive (direction `sub`).  Shared results are stored
+  // by sub-lane 0.  (Link terms are NOT split: selecting a link's frame, COM, velocity and constants per lane costs half of what it saves.)
   SubCtx<T, ROBOT>& C = ch.get();
   using RB = Robot<ROBOT>;
   constexpr int NJ = RB::NJ;
@@ -785,7 +803,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       rank1_sub(IA, U, Dinv);
       SV<T> pa = pA + mul(IA, ck[k]) + U * (u * Dinv);
       if constexpr (k > 0) { add(IA, Ik[k - 1]); pA = pk[k - 1] + pa; }
-      else { C.Ileg[L] = IA; C.pleg[L] = pa; }
+      else if (sub == 0) { C.Ileg[L] = IA; C.pleg[L] = pa; }
     });
   }
   LegResp<T, NJ> LR;
@@ -804,6 +822,54 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) Minv[i][j] = T(0);
+#if SOLO_LEG_QUAD
+  {
+    // column jj = min(sub, NJ - 1) of the response, with the column index a run-time value: the compile-time version below with its
+    // `if constexpr (k > j)` cases turned into selects
+    const int jj = sub < NJ - 1 ? sub : NJ - 1;
+    SV<T> Uj = Uk[0]; T Dj = Dk[0];
+#pragma unroll
+    for (int k = 1; k < NJ; k++) {
+      const bool m = jj == k;
+      Uj.a.x = m ? Uk[k].a.x : Uj.a.x; Uj.a.y = m ? Uk[k].a.y : Uj.a.y; Uj.a.z = m ? Uk[k].a.z : Uj.a.z;
+      Uj.l.x = m ? Uk[k].l.x : Uj.l.x; Uj.l.y = m ? Uk[k].l.y : Uj.l.y; Uj.l.z = m ? Uk[k].l.z : Uj.l.z;
+      Dj = m ? Dk[k] : Dj;
+    }
+    T tt[NJ];
+    SV<T> f = Uj * (-Dj);
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = NJ - 1 - decltype(kc)::value;
+      if constexpr (k == NJ - 1) tt[k] = jj == k ? T(1) : T(0);           // (k > jj: 0; k < jj cannot happen for the outermost joint)
+      else {
+        const T cand = dot(Sk[k], f);
+        const bool below = k < jj;
+        tt[k] = below ? cand : (k == jj ? T(1) : T(0));
+        const SV<T> fn = fma6(Uk[k], -cand * Dk[k], f);
+        f.a.x = below ? fn.a.x : f.a.x; f.a.y = below ? fn.a.y : f.a.y; f.a.z = below ? fn.a.z : f.a.z;
+        f.l.x = below ? fn.l.x : f.l.x; f.l.y = below ? fn.l.y : f.l.y; f.l.z = below ? fn.l.z : f.l.z;
+      }
+    });
+    const SV<T> Gm = f * T(-1);
+    T col[NJ];
+    SV<T> dv = zero6<T>();
+    static_for<NJ>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      T yk;
+      if constexpr (k == 0) yk = tt[0] * Dk[0]; else yk = (tt[k] - dot(Uk[k], dv)) * Dk[k];
+      col[k] = yk;
+      if constexpr (k < NJ - 1) dv = fma6(Sk[k], yk, dv);
+    });
+    // every sub-lane gets every column: quad_perm broadcast from sub-lane j
+    static_for<NJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      LR.G[j].a.x = quad_bcast<j>(Gm.a.x); LR.G[j].a.y = quad_bcast<j>(Gm.a.y); LR.G[j].a.z = quad_bcast<j>(Gm.a.z);
+      LR.G[j].l.x = quad_bcast<j>(Gm.l.x); LR.G[j].l.y = quad_bcast<j>(Gm.l.y); LR.G[j].l.z = quad_bcast<j>(Gm.l.z);
+#pragma unroll
+      for (int k = 0; k < NJ; k++) Minv[k][j] = quad_bcast<j>(col[k]);
+    });
+  }
+  if (sub == 0) C.LR[L] = LR;
+#else
   static_for<NJ>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     T t[NJ];
@@ -825,9 +891,10 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
     });
   });
   C.LR[L] = LR;
+#endif
   // joint-limit rows of this leg: the ones the collision phase selected (C.lsel), slots in joint order
   const int lsel = C.lsel;
-  if ((lsel >> (2 * NJ * L)) & ((1 << (2 * NJ)) - 1)) {
+  if (sub == 0 && ((lsel >> (2 * NJ * L)) & ((1 << (2 * NJ)) - 1))) {
     static_for<NJ>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
 #pragma unroll
@@ -858,6 +925,24 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
       const T lam0 = pp_warm * C.lamp[p];
       const T fric = SEL4(T, lsg, RB::MD.prims[P0].friction, RB::MD.prims[P0 + PS].friction, RB::MD.prims[P0 + 2 * PS].friction,
                           RB::MD.prims[P0 + 3 * PS].friction) * (((C.smask >> p) & 1) ? pp_tm_mu : T(1));
+#if SOLO_LEG_QUAD
+      if (sub < 3) {             // direction d = sub: 0 normal (z), 1 friction x, 2 friction y -- the three rows of the contact side by side
+        const int d = sub;
+        const V3<T> u = mk(d == 1 ? T(1) : T(0), d == 2 ? T(1) : T(0), d == 0 ? T(1) : T(0));
+        SV<T> F{cross(P, u), u};
+        T JL[3] = {T(0), T(0), T(0)}, Y[3];
+        SV<T> f0 = F;
+        static_for<DEPTH>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          JL[k] = dot(Sk[k], F);
+          f0 = fma6(LR.G[k], -JL[k], f0);
+        });
+#pragma unroll
+        for (int r = 0; r < 3; r++) Y[r] = Minv[r][0] * JL[0] + Minv[r][1] * JL[1] + Minv[r][2] * JL[2];
+        park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0), fric,
+                 (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8));
+      }
+#else
       static_for<3>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         V3<T> u = d == 0 ? mk(T(0), T(0), T(1)) : (d == 1 ? mk(T(1), T(0), T(0)) : mk(T(0), T(1), T(0)));
@@ -874,6 +959,7 @@ SNI_SCALAR void phase_leg_rt(CH ch, const PhysParams<T>& pp, const T* lam_prev, 
         park_row(lds, d == 0 ? slot_n : slot_f + (d - 1), f0, JL, Y, P, pen, d == 0 ? lam0 : T(0), fric,
                  (d == 0 ? 0 : (slot_n | 128)) | (L << 5) | (d << 8));
       });
+#endif
     }
   });
 }
@@ -1991,10 +2077,17 @@ SD int substep_team(const PhysParams<T> pp, T* lam_prev, unsigned nstride, const
   if (ui) phase_front_team<T, ROBOT, LDS, CH, true>(ch, pp, lds, t, valid, lead);
   else phase_front_team<T, ROBOT, LDS, CH, false>(ch, pp, lds, t, valid, lead);
   SOLO_PT(1);
-  if (valid && t < 4) {                                                                     // four legs on four lanes
-    if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t);
-    else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t);
+#if SOLO_LEG_QUAD
+  if (valid) {                                                                              // four legs on four quads (phase_leg_rt)
+    if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t >> 2, t & 3);
+    else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t >> 2, t & 3);
   }
+#else
+  if (valid && t < 4) {                                                                     // four legs on four lanes
+    if (ui) phase_leg_rt<T, ROBOT, LDS, CH, true>(ch, pp, lam_prev, nstride, lds, t, 0);
+    else phase_leg_rt<T, ROBOT, LDS, CH, false>(ch, pp, lam_prev, nstride, lds, t, 0);
+  }
+#endif
   SOLO_PT(2);
   if (valid) team_sum_base<T, ROBOT, CH>(ch, t);
   SOLO_PT(3);
