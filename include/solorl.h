@@ -56,7 +56,7 @@ enum { SOLORL_FRICTION_PYRAMID = 0, SOLORL_FRICTION_CONE = 1 };
 
 /* Bumped whenever a struct of this header changes layout or meaning; solorl_abi_version() returns the value the library was built with
  * and a binding compares the two before its first call (a caller built against another layout would hand over short structs). */
-#define SOLORL_ABI_VERSION 4
+#define SOLORL_ABI_VERSION 5
 
 enum {
   SOLORL_OK = 0,
@@ -258,7 +258,8 @@ typedef struct solorl_ppo_batch {
 /* Outputs, all [unit][m] (row index fastest): xt0 = gathered observations [obs_dim][m]; per net (c_ critic, a_ actor) the hidden
  * activations xt1, xt2 [64][m], the pre-activation gradients g1, g2 [64][m] and the head-output gradient gh ([1][m] / [A][m]).
  * Weight gradients are then G^T X products over the rows:  d W0 = g1 xt0^T, d W1 = g2 xt1^T, d Whead = gh xt2^T, biases = row
- * sums of g.  partials [ceil(m/64)][3 + A]: per 64 rows (sum value loss, sum action loss, rows, sum d action-loss / d logstd_a);
+ * sums of g.  partials [ceil(m/32)][3 + A]: per 32 rows (sum value loss, sum action loss, rows, sum d action-loss / d logstd_a; ABI 5:
+ * one row per 32 samples, it was 64);
  * the entropy term of ppo.py:74 does not depend on the samples and is left to the caller. */
 typedef struct solorl_ppo_stage1 {
   float *xt0, *c_xt1, *c_xt2, *c_g1, *c_g2, *c_gh, *a_xt1, *a_xt2, *a_g1, *a_g2, *a_gh, *partials;
@@ -271,7 +272,8 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
  *   loss_sums [3 + A]  += (sum value loss, sum action loss, rows, sum d action-loss / d logstd) of this mini-batch,
  *   logstd_sum [1]     += sum_a logstd_a            (entropy = 0.5 + log sqrt(2 pi) + mean_a logstd_a, policy.py:56)
  *   logstd             = sum d action-loss / d logstd - entropy_coef / A       (the complete gradient of ppo.py:74's loss)
- *   scratch            >= ceil(m / 512) * solorl_ppo_grad_count(obs_dim, act_dim) floats of working memory.
+ *   scratch            >= solorl_ppo_scratch_count(obs_dim, act_dim, m) floats of working memory (one solorl_ppo_grad_count block per
+ *                      chunk of rows; ABI 5 cut the rows into ~170 chunks instead of ceil(m / 512)).
  * Sums are taken in a fixed order: results are reproducible run to run. */
 typedef struct solorl_ppo_grads {
   float *critic_w0, *critic_b0, *critic_w1, *critic_b1, *critic_w2, *critic_b2;
@@ -283,6 +285,8 @@ int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage
                            void* stream);
 /* number of weight + bias elements of the actor-critic except logstd (one scratch chunk) */
 int solorl_ppo_grad_count(int obs_dim, int act_dim);
+/* floats of solorl_ppo_grads.scratch that solorl_ppo_grad_stage2 needs for a mini-batch of m rows (0 for m < 1) */
+int solorl_ppo_scratch_count(int obs_dim, int act_dim, int m);
 
 /* Gradient-norm clip + Adam step over the 13 parameter tensors in one launch: nn.utils.clip_grad_norm_(max_grad_norm)
  * (agents/ppo/ppo.py:75-76; coefficient max_norm / (norm + 1e-6) clamped to 1) followed by torch.optim.Adam's update (:32, :77:

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SOLORL_LIB") or os.path.join(os.path.dirname(os.path.
 SYMBOLS = ("solorl_default_config", "solorl_create", "solorl_destroy", "solorl_dims", "solorl_reset", "solorl_step",
            "solorl_get_observation", "solorl_increment_curriculum", "solorl_get_state", "solorl_set_state", "solorl_get_property",
            "solorl_compute_returns", "solorl_ppo_loss", "solorl_policy_act", "solorl_ppo_grad_stage1", "solorl_ppo_grad_stage2", "solorl_ppo_grad_count", "solorl_ppo_clip_adam", "solorl_last_error", "solorl_version",
-           "solorl_abi_version", "solorl_step_act")
+           "solorl_abi_version", "solorl_step_act", "solorl_ppo_scratch_count")
 
 
 class PolicyParams(C.Structure):            # solorl_policy_params
@@ -80,6 +80,8 @@ def lib():
         L.solorl_ppo_grad_stage1.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoBatch), C.POINTER(PpoStage1), C.c_int, C.c_void_p]
         L.solorl_ppo_grad_stage2.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoStage1), C.c_int, C.POINTER(PpoGrads), C.c_int, C.c_void_p]
         L.solorl_ppo_grad_count.argtypes = [C.c_int, C.c_int]
+        L.solorl_ppo_scratch_count.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.solorl_ppo_scratch_count.restype = C.c_int
         L.solorl_ppo_clip_adam.argtypes = [C.POINTER(PolicyParams), C.POINTER(PpoGrads), C.POINTER(AdamState), C.c_int, C.c_void_p]
         for s in SYMBOLS:
             getattr(L, s)

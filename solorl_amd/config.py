@@ -14,7 +14,7 @@ TASK_STAND, TASK_WALK, TASK_POINTGOAL = 0, 1, 2
 CONTROL_TORQUE, CONTROL_PD = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 FRICTION_PYRAMID, FRICTION_CONE = 0, 1
-ABI_VERSION = 4            # SOLORL_ABI_VERSION (include/solorl.h)
+ABI_VERSION = 5            # SOLORL_ABI_VERSION (include/solorl.h)
 
 TASKS = {"stand": TASK_STAND, "walk": TASK_WALK, "pointgoal": TASK_POINTGOAL}
 CONTROLS = {"torque": CONTROL_TORQUE, "pd": CONTROL_PD, "fpd": CONTROL_PD, "fixed_pd": CONTROL_PD}

@@ -497,94 +497,70 @@ SD void team_current_state(const SubCtx<T, ROBOT>& C, int task, int D, int t, T 
 // log-std) for the env whose observation this team has just produced.  Why here: at 4096 envs the launch lasts as long as its slowest
 // wavefront while the MEAN wavefront is done after half that time, and the rollout's next launch -- the policy --
 // can only start when the launch has drained; computed by each wavefront for its own four envs the policy rides in that idle time and
-// a rollout step is ONE launch.  16 lanes per env: lane t owns hidden units 4t .. 4t+3 of both nets, activations are exchanged through
-// the (now dead) row storage in LDS, weights come from L2 as float4 rows (PyTorch layout); lanes 0..A-1 finish the actor head, lane 15
-// the critic head.  ~1700 instructions per wavefront (~3 us) against a 15 us kernel + launch gap.  O % 4 == 0 (one history level).
+// a rollout step is ONE launch.  Hidden layers: one unit per lane for the wavefront's four envs (pol_layer); activations are exchanged
+// through the (now dead) row storage in LDS, weights come from L2 as float4 rows (PyTorch layout); heads: 16 lanes per env, lanes 0..A-1
+// the actor head, lane 15 the critic head.  ~1500 instructions per wavefront (~3 us) against a 15 us kernel + launch gap.  O % 4 == 0
+// (one history level).
 constexpr float POL_HALF_LOG_2PI = 0.91893853320467274178f;
 constexpr unsigned POL_ENV_BYTES = 2496;     // per-env slice of the row storage (26 rows x 24 values x 4 B): obs <= 96, h1 128, h2 128 floats
-SD float pol_tanh(float x) { const float e = __expf(2.0f * x); return 1.0f - 2.0f * __frcp_rn(1.0f + e); }   // as solorl_ppo.hip tanh_fast
+SD float pol_tanh(float x) { const float e = __expf(2.0f * x); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e); }   // as solorl_ppo.hip tanh_fast
 typedef float nfloat4 __attribute__((ext_vector_type(4)));          // (native vector: HIP's float4 class cannot be read through an address-space pointer)
 typedef __attribute__((address_space(1))) const nfloat4 gfloat4;
 SD float pol_dot4(nfloat4 w, nfloat4 x, float acc) { return fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, acc)))); }
-// A lone wavefront has nothing to hide a load's latency behind, so the weight loads are issued in explicit BATCHES (POL_KB input chunks x 8
-// rows = 32 float4 per batch) with a compiler barrier behind them that also re-defines the loaded values -- left to itself the scheduler
-// kept ~8 loads in flight and waited for them one or two at a time (19 exposed L2 round trips in layer 1 alone: the tail took 29 us).
-constexpr int POL_KB = 4;
+// A lone wavefront has nothing to hide a load's latency behind, so the weight loads are issued in explicit BATCHES (16-20 float4 per
+// batch) with a compiler barrier behind them that also re-defines the loaded values -- left to itself the scheduler kept ~8 loads in
+// flight and waited for them one or two at a time (19 exposed L2 round trips in layer 1 alone: the tail took 29 us).
 #define POL_PIN4(x) asm volatile("" : "+v"(x))
+// Hidden layers, one UNIT per lane: lane L of the wavefront computes unit L of both nets for all FOUR envs of the wavefront -- a weight row
+// is loaded once per wavefront and multiplied with four observation vectors (LDS broadcast reads) instead of once per env: 70 float4
+// weight loads per lane for the two layers instead of 280.  Batches of KB input chunks x 2 nets behind a value-redefining barrier,
+// as before.
+template <int KB>
+SD void pol_layer(const float* wc_, const float* wa_, const float* bc_, const float* ba_, int K4, int lane, unsigned xoff, unsigned xoff_a, unsigned yoff) {
+  gfloat4* wc = (gfloat4*)(wc_ + (size_t)lane * 4 * K4);
+  gfloat4* wa = (gfloat4*)(wa_ + (size_t)lane * 4 * K4);
+  float c[4], a[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { c[e] = bc_[lane]; a[e] = ba_[lane]; }
+#pragma unroll 1
+  for (int k0 = 0; k0 < K4; k0 += KB) {
+    nfloat4 wcb[KB], wab[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; kk++) {
+      const int k = k0 + kk < K4 ? k0 + kk : K4 - 1;          // (past the end: the last chunk again, not accumulated)
+      wcb[kk] = wc[k]; wab[kk] = wa[k];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < KB; kk++) { POL_PIN4(wcb[kk]); POL_PIN4(wab[kk]); }
+#pragma unroll
+    for (int kk = 0; kk < KB; kk++)
+      if (k0 + kk < K4) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const nfloat4 xc = reinterpret_cast<const nfloat4*>(solo_smem + e * POL_ENV_BYTES + xoff)[k0 + kk];
+          const nfloat4 xa = xoff_a == xoff ? xc : reinterpret_cast<const nfloat4*>(solo_smem + e * POL_ENV_BYTES + xoff_a)[k0 + kk];
+          c[e] = pol_dot4(wcb[kk], xc, c[e]); a[e] = pol_dot4(wab[kk], xa, a[e]);
+        }
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    float* y = reinterpret_cast<float*>(solo_smem + e * POL_ENV_BYTES + yoff);
+    y[lane] = pol_tanh(c[e]); y[64 + lane] = pol_tanh(a[e]);
+  }
+}
+
 template <int A>
 SD void policy_tail_team(const PolicyTail& P, int O, int col, int t, idx_t env, bool valid) {
   float* const buf = reinterpret_cast<float*>(solo_smem + (unsigned)col * POL_ENV_BYTES);
-  const nfloat4* const obs4 = reinterpret_cast<const nfloat4*>(buf);
-  float* const h1 = buf + 96;              // [critic 64 | actor 64]
-  float* const h2 = buf + 224;
-  const int O4 = O >> 2;
-  float c[4], a[4];
-  {   // layer 1
-    gfloat4* wc = (gfloat4*)(P.cw0 + (size_t)(4 * t) * O);
-    gfloat4* wa = (gfloat4*)(P.aw0 + (size_t)(4 * t) * O);
-#pragma unroll
-    for (int u = 0; u < 4; u++) { c[u] = P.cb0[4 * t + u]; a[u] = P.ab0[4 * t + u]; }
-#pragma unroll 1
-    for (int k0 = 0; k0 < O4; k0 += POL_KB) {
-      nfloat4 wcb[POL_KB][4], wab[POL_KB][4], xb[POL_KB];
-#pragma unroll
-      for (int kk = 0; kk < POL_KB; kk++) {
-        const int k = k0 + kk < O4 ? k0 + kk : O4 - 1;          // (past the end: the last chunk again, not accumulated)
-        xb[kk] = obs4[k];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { wcb[kk][u] = wc[u * O4 + k]; wab[kk][u] = wa[u * O4 + k]; }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int kk = 0; kk < POL_KB; kk++) {
-        POL_PIN4(xb[kk]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) { POL_PIN4(wcb[kk][u]); POL_PIN4(wab[kk][u]); }
-      }
-#pragma unroll
-      for (int kk = 0; kk < POL_KB; kk++)
-        if (k0 + kk < O4) {
-#pragma unroll
-          for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wcb[kk][u], xb[kk], c[u]); a[u] = pol_dot4(wab[kk][u], xb[kk], a[u]); }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { h1[4 * t + u] = pol_tanh(c[u]); h1[64 + 4 * t + u] = pol_tanh(a[u]); }
-  }
+  float* const h2 = buf + 224;              // per env: obs at 0 (<= 96 floats), h1 at 96 [critic 64 | actor 64], h2 at 224
+  const int lane = threadIdx.x & 63;
+  pol_layer<10>(P.cw0, P.aw0, P.cb0, P.ab0, O >> 2, lane, 0u, 0u, 96u * 4u);                 // layer 1: both nets read the observation
+  TEAM_SYNC();
+  pol_layer<8>(P.cw1, P.aw1, P.cb1, P.ab1, 16, lane, 96u * 4u, 160u * 4u, 224u * 4u);      // layer 2: critic reads h1[0..63], actor h1[64..127]
   static_assert(A < 15, "the critic head sits on lane 15");
   const bool head = t < A || t == 15;
-  TEAM_SYNC();
-  {   // layer 2
-    gfloat4* wc = (gfloat4*)(P.cw1 + (size_t)(4 * t) * 64);
-    gfloat4* wa = (gfloat4*)(P.aw1 + (size_t)(4 * t) * 64);
-    const nfloat4* xc = reinterpret_cast<const nfloat4*>(h1); const nfloat4* xa = reinterpret_cast<const nfloat4*>(h1 + 64);
-#pragma unroll
-    for (int u = 0; u < 4; u++) { c[u] = P.cb1[4 * t + u]; a[u] = P.ab1[4 * t + u]; }
-#pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += POL_KB) {
-      nfloat4 wcb[POL_KB][4], wab[POL_KB][4], xcb[POL_KB], xab[POL_KB];
-#pragma unroll
-      for (int kk = 0; kk < POL_KB; kk++) {
-        xcb[kk] = xc[k0 + kk]; xab[kk] = xa[k0 + kk];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { wcb[kk][u] = wc[u * 16 + k0 + kk]; wab[kk][u] = wa[u * 16 + k0 + kk]; }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int kk = 0; kk < POL_KB; kk++) {
-        POL_PIN4(xcb[kk]); POL_PIN4(xab[kk]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) { POL_PIN4(wcb[kk][u]); POL_PIN4(wab[kk][u]); }
-      }
-#pragma unroll
-      for (int kk = 0; kk < POL_KB; kk++) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) { c[u] = pol_dot4(wcb[kk][u], xcb[kk], c[u]); a[u] = pol_dot4(wab[kk][u], xab[kk], a[u]); }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { h2[4 * t + u] = pol_tanh(c[u]); h2[64 + 4 * t + u] = pol_tanh(a[u]); }
-  }
   TEAM_SYNC();
   // heads: lane t < A -> mean_t (and the action, its log-prob term), lane 15 -> value
   float out = 0.f;

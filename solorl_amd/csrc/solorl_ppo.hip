@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/solorl.h"
 
@@ -37,13 +38,18 @@ constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 #define CRITIC_PASS P.critic_w0, P.critic_b0, P.critic_w1, P.critic_b1, P.critic_w2, P.critic_b2
 #define ACTOR_PASS P.actor_w0, P.actor_b0, P.actor_w1, P.actor_b1, P.mean_w, P.mean_b, P.logstd
 
-// tanh(x) = 1 - 2 / (1 + e^(2x)) on the hardware exp2 / reciprocal: 6 instructions instead of libm's ~40, absolute error
-// <= 2e-7 over the whole line (saturates cleanly: e^(2x) = inf -> 1, 0 -> -1) -- the level of the f32 sums that feed it.  The
-// relative error near 0 is larger (1e-4 at |x| = 1e-3), which an activation bounded by 1 does not care about.
+// tanh(x) = 1 - 2 / (1 + e^(2x)) on the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): 5 instructions instead of libm's
+// ~40, absolute error <= 3e-7 over the whole line (saturates cleanly: e^(2x) = inf -> 1, 0 -> -1) -- the level of the f32 sums that
+// feed it.  The relative error near 0 is larger (1e-4 at |x| = 1e-3), which an activation bounded by 1 does not care about.
+// (__frcp_rn is the correctly rounded reciprocal: a 10-instruction division sequence, 64 times per net and tile -- a fifth of stage 1's
+// vector instructions.)
 __device__ __forceinline__ float tanh_fast(float x) {
   const float e = __expf(2.0f * x);
-  return 1.0f - 2.0f * __frcp_rn(1.0f + e);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
+
+template <typename F, int... I> __device__ __forceinline__ void unrolled_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void unrolled(F&& f) { unrolled_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
@@ -53,44 +59,73 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 // ------------------------------------------------------------------------------------------------ stage 2 / 3 bookkeeping
 // Stage 2 (MFMA, below) leaves per-chunk partial products in scratch; stage 3 adds them in a fixed order (reproducible, no
-// atomics) straight into the parameters' gradients.  X carries a row of ones, so column K of a product is the bias gradient.
-struct LayerDesc { const float* g; const float* x; float* wgrad; float* bgrad; int U, K1, off, tile0; };   // K1 = inputs + 1
-struct Stage2Args { LayerDesc L[6]; int m, nchunks, total, ntiles; float* scratch; };
+// atomics) straight into the parameters' gradients.  Column K of a product is the bias gradient (the row sum of G).
+// K1 = inputs + 1; off: the layer's first element in the flat gradient order; the layer's rows are cut into nchunks chunks of mchunk rows
+// (wavefronts wave0 .. wave0 + nchunks - 1 of stage 2), chunk c's partial product sits at scratch[sbase + c U K1 ..]
+struct LayerDesc { const float* g; const float* x; float* wgrad; float* bgrad; int U, K1, off, nchunks, mchunk, wave0, sbase, reserved; };
+struct Stage2Args { LayerDesc L[6]; int m, total, nwaves, reserved; float* scratch; };
 
-// stage 3: add the chunks (fixed order) into the parameters' gradients; the last block finishes the log-std gradient and the
-// running loss sums from stage 1's per-wavefront partials
+// stage 3: add the chunks (fixed order) into the parameters' gradients; 3 + A more workgroups finish the log-std gradient and the
+// running loss sums from stage 1's per-wavefront partials, one column each (a single workgroup walking the columns one after the
+// other was the kernel's critical path: 8 us at 512 rows of partials, 18 us at 1024)
 struct Stage3Args { Stage2Args S; const float* partials; int nwaves, A; const float* logstd; float* logstd_grad; float* loss_sums;
                     float* logstd_sum; float entropy_coef; };
 __global__ void __launch_bounds__(256) ppo_grad_stage3_kernel(const Stage3Args T) {
   const Stage2Args& S = T.S;
-  if (blockIdx.x == gridDim.x - 1) {          // 3 + A column sums of partials [nwaves][3 + A], one wavefront each column group
-    const int nc = 3 + T.A, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c = wv; c < nc; c += 4) {
-      float a = 0.f;
-      for (int w = lane; w < T.nwaves; w += 64) a += T.partials[(size_t)w * nc + c];
-      a = wave_sum(a);
-      if (lane == 0) {
-        T.loss_sums[c] += a;
-        if (c >= 3) T.logstd_grad[c - 3] = a - T.entropy_coef / (float)T.A;      // entropy = mean over batch and dims of logstd + const
-      }
+  const int nel = (S.total + 15) / 16;        // element workgroups; then one workgroup per column of partials [nwaves][3 + A]
+  if ((int)blockIdx.x >= nel) {
+    __shared__ float red[4];
+    const int nc = 3 + T.A, c = blockIdx.x - nel;
+    float a = 0.f;
+    for (int w0 = 0; w0 < T.nwaves; w0 += 2048) {         // (eight independent loads per thread and trip)
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int w = w0 + threadIdx.x + 256 * i; v[i] = T.partials[(size_t)min(w, T.nwaves - 1) * nc + c]; if (w >= T.nwaves) v[i] = 0.f; }
+      a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    if (threadIdx.x == 0) { float e = 0.f; for (int a = 0; a < T.A; ++a) e += T.logstd[a]; *T.logstd_sum += e; }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a = (red[0] + red[1]) + (red[2] + red[3]);
+      T.loss_sums[c] += a;
+      if (c >= 3) T.logstd_grad[c - 3] = a - T.entropy_coef / (float)T.A;      // entropy = mean over batch and dims of logstd + const
+      if (c == 0) { float e = 0.f; for (int k = 0; k < T.A; ++k) e += T.logstd[k]; *T.logstd_sum += e; }
+    }
     return;
   }
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= S.total) return;
-  int li = 0;
+  // 16 elements x 16 chunk groups per workgroup: thread (el, grp) adds chunks grp, grp + 16, ... of its element (all loads independent:
+  // one memory round trip for up to 256 chunks), the groups' sums are added in a fixed order through LDS
+  __shared__ float part[16][17];
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const bool on = blockIdx.x * 16 + el < S.total;
+  const int e = on ? blockIdx.x * 16 + el : S.total - 1;
+  LayerDesc L = S.L[0];                  // (selects: a dynamic index into the argument struct would be served from scratch)
 #pragma unroll
-  for (int i = 1; i < 6; ++i) if (e >= S.L[i].off) li = i;
-  const LayerDesc& L = S.L[li];
-  float a4[4] = {0.f, 0.f, 0.f, 0.f};                       // four interleaved sums: the loads of a group are independent
-  int c = 0;
-  for (; c + 4 <= S.nchunks; c += 4) {
+  for (int i = 1; i < 6; ++i) if (e >= S.L[i].off) L = S.L[i];
+  const float* __restrict__ src = S.scratch + L.sbase + (e - L.off);
+  const size_t stride = (size_t)L.U * L.K1;
+  float a16[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a4[i] += S.scratch[(size_t)(c + i) * S.total + e];
+  for (int i = 0; i < 16; ++i) {           // (unconditional loads from a clamped chunk, then a select: a branch per load serialises them)
+    const int c = grp + 16 * i;
+    a16[i] = src[(size_t)min(c, L.nchunks - 1) * stride];
   }
-  for (; c < S.nchunks; ++c) a4[0] += S.scratch[(size_t)c * S.total + e];
-  const float a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { asm volatile("" : "+v"(a16[i])); if (grp + 16 * i >= L.nchunks) a16[i] = 0.f; }     // (pinned: the loads stay unconditional)
+  float rem = 0.f;
+  if (on) for (int c = grp + 256; c < L.nchunks; c += 16) rem += src[(size_t)c * stride];      // (more than 256 chunks: not with stage2_plan's ~1024 wavefronts)
+#pragma unroll
+  for (int d = 8; d > 0; d >>= 1)
+#pragma unroll
+    for (int i = 0; i < d; ++i) a16[i] += a16[i + d];
+  part[grp][el] = a16[0] + rem;
+  __syncthreads();
+  if (grp != 0 || !on) return;
+  float a = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) a += part[g][el];
   const int q = e - L.off, u = q / L.K1, k = q % L.K1;
   if (k == L.K1 - 1) L.bgrad[u] = a; else L.wgrad[u * (L.K1 - 1) + k] = a;
 }
@@ -108,12 +143,22 @@ __global__ void __launch_bounds__(256) ppo_grad_stage3_kernel(const Stage3Args T
 // is W[unit 32 mt + c][input 8 q + 4 h + t]: a lane reads 16 consecutive bytes of one weight row per q -- all weights of a net
 // (forward and transposed, 256 VGPRs) are loaded once per wavefront and stay in registers while it walks over its row tiles.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef SOLO_PPO_NOMFMA      // dev experiment (tools/dev/build_ppo_variant.py): what the kernels cost without their matrix products
+#define MFMA32(a, b, c) (c)
+#else
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
 
 template <int O, int NOUT, bool BACKWARD> struct NetRegs {
   static constexpr int QO = (O + 7) / 8, QA = (NOUT + 7) / 8;
   float a0[2][QO][4], a1[2][8][4], ah[8][4];
   float aht[BACKWARD ? 2 : 1][QA][4], a1t[BACKWARD ? 2 : 1][BACKWARD ? 8 : 1][4];
+  // operand access, four consecutive contraction steps at a time (the interface NetLds shares)
+  __device__ __forceinline__ float4 A0(int mt, int q) const { return make_float4(a0[mt][q][0], a0[mt][q][1], a0[mt][q][2], a0[mt][q][3]); }
+  __device__ __forceinline__ float4 A1(int mt, int q) const { return make_float4(a1[mt][q][0], a1[mt][q][1], a1[mt][q][2], a1[mt][q][3]); }
+  __device__ __forceinline__ float4 AH(int q) const { return make_float4(ah[q][0], ah[q][1], ah[q][2], ah[q][3]); }
+  __device__ __forceinline__ float4 AHT(int mt, int q) const { return make_float4(aht[mt][q][0], aht[mt][q][1], aht[mt][q][2], aht[mt][q][3]); }
+  __device__ __forceinline__ float4 A1T(int mt, int q) const { return make_float4(a1t[mt][q][0], a1t[mt][q][1], a1t[mt][q][2], a1t[mt][q][3]); }
   __device__ __forceinline__ void load(NET_ARGS, int c, int h) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -158,16 +203,82 @@ template <int O, int NOUT, bool BACKWARD> struct NetRegs {
   }
 };
 
+// The same operands held ONCE per workgroup in LDS, as the per-lane register image of NetRegs: entry e = one (array, tile, q) of four
+// consecutive contraction steps, stored [e][lane] as float4 -- a wavefront's ds_read_b128 of an entry is 1 KB of consecutive bytes
+// (conflict-free), feeds four MFMAs (256 cycles), and nothing stays in registers between uses.  Stage 1 held the net in 250 registers
+// per lane, spilled its activations to AGPRs and scratch around them (256 + 256 registers, 160 B of scratch) and re-read the 64 KB
+// image per wavefront; with the image in LDS four wavefronts share one copy and two workgroups fit a CU.
+template <int O, int NOUT> struct NetLds {
+  static constexpr int QO = (O + 7) / 8, QA = (NOUT + 7) / 8;
+  static constexpr int E_A0 = 0, E_A1 = E_A0 + 2 * QO, E_AH = E_A1 + 16, E_AHT = E_AH + 8, E_A1T = E_AHT + 2 * QA, NE = E_A1T + 16;
+  static constexpr int BYTES = NE * 64 * 16;
+  const float4* img;        // + lane
+  __device__ __forceinline__ float4 A0(int mt, int q) const { return img[(E_A0 + mt * QO + q) * 64]; }
+  __device__ __forceinline__ float4 A1(int mt, int q) const { return img[(E_A1 + mt * 8 + q) * 64]; }
+  __device__ __forceinline__ float4 AH(int q) const { return img[(E_AH + q) * 64]; }
+  __device__ __forceinline__ float4 AHT(int mt, int q) const { return img[(E_AHT + mt * QA + q) * 64]; }
+  __device__ __forceinline__ float4 A1T(int mt, int q) const { return img[(E_A1T + mt * 8 + q) * 64]; }
+  // entry e of the image for lane (c, h), from the PyTorch-layout parameters (what NetRegs::load puts into registers)
+  static __device__ __forceinline__ float4 entry(int e, NET_ARGS, int c, int h) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < E_A1) {
+      const int mt = e / QO, q = e % QO, i0 = 8 * q + 4 * h;
+      const float* wr = w0 + (size_t)(32 * mt + c) * O + i0;
+      if constexpr (O % 4 == 0) { if (i0 < O) return *reinterpret_cast<const float4*>(wr); }
+      else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (i0 + t < O) v[t] = wr[t];
+      }
+    } else if (e < E_AH) {
+      const int mt = (e - E_A1) / 8, q = (e - E_A1) % 8;
+      return *reinterpret_cast<const float4*>(w1 + (32 * mt + c) * H + 8 * q + 4 * h);
+    } else if (e < E_AHT) {
+      if (c < NOUT) return *reinterpret_cast<const float4*>(wh + c * H + 8 * (e - E_AH) + 4 * h);
+    } else if (e < E_A1T) {
+      const int mt = (e - E_AHT) / QA, q = (e - E_AHT) % QA;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const int a = 8 * q + 4 * h + t; if (a < NOUT) v[t] = wh[a * H + 32 * mt + c]; }
+    } else {
+      const int mt = (e - E_A1T) / 8, q = (e - E_A1T) % 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = w1[(8 * q + 4 * h + t) * H + 32 * mt + c];
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
 // the unit a D register belongs to
 __device__ __forceinline__ constexpr int unit_of(int mt, int v, int h) { return 32 * mt + 8 * (v >> 2) + 4 * h + (v & 3); }
 
-// layers 1 and 2 and the head for one 32-row tile; x = the lane's row, inputs 8 q + 4 h .. + 3 per q.  After the call h1, h2 hold
+// layers 1 and 2 and the head for one 32-row tile; X = the lane's row (loaded by the caller: its latency is the caller's to hide).  After the call h1, h2 hold
 // tanh activations (D layout), dh the head outputs (unit = unit_of(0, v, h), valid below NOUT).
-template <int O, int NOUT, bool BW, typename S1, typename S2>
-__device__ __forceinline__ void mfma_forward(const NetRegs<O, NOUT, BW>& R, const float* __restrict__ b0, const float* __restrict__ b1,
-                                             const float* __restrict__ bh, const float* __restrict__ xrow, int h, f32x16 (&h1)[2],
+__device__ __forceinline__ float comp4(const float4& f, int t) { return t == 0 ? f.x : (t == 1 ? f.y : (t == 2 ? f.z : f.w)); }   // (t: unrolled, compile-time)
+
+// the lane's share of an observation row: inputs 8 q + 4 h .. + 3 for every q (zero past O)
+template <int O> struct ObsRow {
+  static constexpr int QO = (O + 7) / 8;
+  float x[QO][4];
+  __device__ __forceinline__ void load(const float* __restrict__ xrow, int h) {
+#pragma unroll
+    for (int q = 0; q < QO; ++q) {
+      const int i0 = 8 * q + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[q][t] = 0.f;
+      if constexpr (O % 4 == 0) {
+        if (i0 < O) { const float4 xv = *reinterpret_cast<const float4*>(xrow + i0); x[q][0] = xv.x; x[q][1] = xv.y; x[q][2] = xv.z; x[q][3] = xv.w; }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (i0 + t < O) x[q][t] = xrow[i0 + t];
+      }
+    }
+  }
+};
+
+template <int O, int NOUT, typename WT, typename S1, typename S2>
+__device__ __forceinline__ void mfma_forward(const WT& R, const float* __restrict__ b0, const float* __restrict__ b1,
+                                             const float* __restrict__ bh, const ObsRow<O>& X, int h, f32x16 (&h1)[2],
                                              f32x16 (&h2)[2], f32x16& dh, S1&& store_x, S2&& store_h) {
-  constexpr int QO = NetRegs<O, NOUT, BW>::QO;
+  constexpr int QO = WT::QO;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -177,18 +288,13 @@ __device__ __forceinline__ void mfma_forward(const NetRegs<O, NOUT, BW>& R, cons
 #pragma unroll
   for (int q = 0; q < QO; ++q) {
     const int i0 = 8 * q + 4 * h;
-    float x[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (O % 4 == 0) {
-      if (i0 < O) { const float4 xv = *reinterpret_cast<const float4*>(xrow + i0); x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w; }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) if (i0 + t < O) x[t] = xrow[i0 + t];
-    }
+    const float (&x)[4] = X.x[q];
     if (i0 < O) store_x(i0, x);
+    const float4 wa = R.A0(0, q), wb = R.A0(1, q);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      h1[0] = MFMA32(R.a0[0][q][t], x[t], h1[0]);
-      h1[1] = MFMA32(R.a0[1][q][t], x[t], h1[1]);
+      h1[0] = MFMA32(comp4(wa, t), x[t], h1[0]);
+      h1[1] = MFMA32(comp4(wb, t), x[t], h1[1]);
     }
   }
 #pragma unroll
@@ -199,9 +305,13 @@ __device__ __forceinline__ void mfma_forward(const NetRegs<O, NOUT, BW>& R, cons
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      h2[0] = MFMA32(R.a1[0][4 * mt + (v >> 2)][v & 3], h1[mt][v], h2[0]);
-      h2[1] = MFMA32(R.a1[1][4 * mt + (v >> 2)][v & 3], h1[mt][v], h2[1]);
+    for (int qq = 0; qq < 4; ++qq) {
+      const float4 wa = R.A1(0, 4 * mt + qq), wb = R.A1(1, 4 * mt + qq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        h2[0] = MFMA32(comp4(wa, t), h1[mt][4 * qq + t], h2[0]);
+        h2[1] = MFMA32(comp4(wb, t), h1[mt][4 * qq + t], h2[1]);
+      }
     }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -211,7 +321,11 @@ __device__ __forceinline__ void mfma_forward(const NetRegs<O, NOUT, BW>& R, cons
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) dh = MFMA32(R.ah[4 * mt + (v >> 2)][v & 3], h2[mt][v], dh);
+    for (int qq = 0; qq < 4; ++qq) {
+      const float4 wa = R.AH(4 * mt + qq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dh = MFMA32(comp4(wa, t), h2[mt][4 * qq + t], dh);
+    }
 }
 
 // ---------------------------------------------------------------- act on MFMA: grid (ceil(n / 32), 2), one wavefront per 32 rows
@@ -225,7 +339,9 @@ __device__ __forceinline__ void act_net_mfma(NET_ARGS, const float* __restrict__
   NetRegs<O, NOUT, false> R;
   R.load(w0, b0, w1, b1, wh, bh, c, h);
   f32x16 h1[2], h2[2], dh;
-  mfma_forward<O, NOUT, false>(R, b0, b1, bh, obs + (size_t)r * O, h, h1, h2, dh, [](int, const float (&)[4]) {}, [](int, f32x16 (&)[2]) {});
+  ObsRow<O> X;
+  X.load(obs + (size_t)r * O, h);
+  mfma_forward<O, NOUT>(R, b0, b1, bh, X, h, h1, h2, dh, [](int, const float (&)[4]) {}, [](int, f32x16 (&)[2]) {});
   if constexpr (!ACTOR) {
     if (on && h == 0) value_out[row] = dh[0];
   } else {
@@ -254,41 +370,70 @@ policy_act_mfma_kernel(CRITIC_ARGS, ACTOR_ARGS, const float* __restrict__ obs, c
   else act_net_mfma<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, obs, noise, n, value_out, action_out, logp_out);
 }
 
-// ---------------------------------------------------------------- stage 1 on MFMA: grid (ceil(m / 64), 2), one wavefront walks two
-// 32-row tiles (= rows 64 b .. 64 b + 63, so partials keep one row per 64 samples) with its net's weights resident
+// ---------------------------------------------------------------- stage 1 on MFMA: grid (ceil(m / 128), 2), workgroups of four wavefronts,
+// one net per workgroup with its operand image in LDS (NetLds), one 32-row tile per wavefront (= one row of partials per 32 samples)
 template <int O, int A, bool ACTOR>
 __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict__ logstd, const solorl_ppo_batch& B, float* xt0, float* xt1,
-                                              float* xt2, float* g1, float* g2, float* gh, float* partials) {
+                                              float* xt2, float* g1, float* g2, float* gh, float* partials, float4* image) {
   constexpr int NOUT = ACTOR ? A : 1;
-  using NR = NetRegs<O, NOUT, true>;
-  const int l = threadIdx.x, c = l & 31, h = l >> 5, m = B.m;
-  NR R;
-  R.load(w0, b0, w1, b1, wh, bh, c, h);
+  using NR = NetLds<O, NOUT>;
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, c = l & 31, h = l >> 5, m = B.m;
+  // the tile's row: its index through the permutation, then its observation and its scalars -- issued BEFORE the image is filled, so that
+  // the two dependent memory round trips run under the fill instead of after it
+  const int tile0 = (blockIdx.x * 4 + wave) * 32;
+  const int row = tile0 + c;
+  const bool on = row < m;
+  const int r = on ? row : m - 1;
+#ifdef SOLO_S1_NOSTORE               // dev experiment (tools/dev/build_ppo_variant.py): the [unit][row] stores compiled but never executed
+  const bool st = on && m < 0;
+#else
+  const bool st = on;
+#endif
+  const long long s = B.perm[*B.offset + r];
+  ObsRow<O> X;
+  X.load(B.obs + (size_t)s * O, h);
+  const float sc_ret = B.ret[s], sc_vp = B.vpred[s], sc_adv = B.adv[s], sc_olp = B.old_logp[s];
+  float sc_act[ACTOR ? 16 : 1] = {};           // the row's actions, in the head's D layout
+  if constexpr (ACTOR) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int a = unit_of(0, v, h);
+      if ((8 * (v >> 2) + (v & 3)) < A) sc_act[v] = B.actions[(size_t)s * A + min(a, A - 1)];
+    }
+  }
+  // fill: entry e by wavefront e mod 4, all loads of a wavefront in flight together
+  {
+    float4 v[(NR::NE + 3) / 4];
+#pragma unroll
+#ifdef SOLO_S1_NOFILL          // dev experiment: the image without its global loads
+    for (int i = 0; i < (NR::NE + 3) / 4; ++i) v[i] = make_float4(0.01f * c, 0.02f, -0.01f * h, 0.03f);
+#else
+    for (int i = 0; i < (NR::NE + 3) / 4; ++i) { const int e = 4 * i + wave; if (e < NR::NE) v[i] = NR::entry(e, w0, b0, w1, b1, wh, bh, c, h); }
+#endif
+#pragma unroll
+    for (int i = 0; i < (NR::NE + 3) / 4; ++i) { const int e = 4 * i + wave; if (e < NR::NE) image[e * 64 + l] = v[i]; }
+  }
+  __syncthreads();
+  const NR R{image + l};
+  if (tile0 >= m) return;
   const float inv_m = 1.0f / (float)m;
   float loss_acc = 0.f, gls_acc[ACTOR ? 16 : 1] = {};
-  int rows_here = 0;
-#pragma unroll 1
-  for (int tile = 0; tile < 2; ++tile) {
-    const int row = blockIdx.x * 64 + tile * 32 + c;
-    if (blockIdx.x * 64 + tile * 32 >= m) break;
-    const bool on = row < m;
-    const int r = on ? row : m - 1;
-    rows_here += min(m - (blockIdx.x * 64 + tile * 32), 32);
-    const long long s = B.perm[*B.offset + r];
+  const int rows_here = min(m - tile0, 32);
+  {
     f32x16 h1[2], h2[2], dh;
     auto store_units = [&](float* arr, f32x16 (&a)[2]) {
-      if (on) {
+      if (st) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int v = 0; v < 16; ++v) arr[(size_t)unit_of(mt, v, h) * m + row] = a[mt][v];
+          for (int v = 0; v < 16; ++v) arr[(unsigned)(unit_of(mt, v, h) * m + row)] = a[mt][v];     // (32-bit element offsets: the arrays are < 2^31 elements, checked by the host)
       }
     };
-    mfma_forward<O, NOUT, true>(R, b0, b1, bh, B.obs + (size_t)s * O, h, h1, h2, dh,
+    mfma_forward<O, NOUT>(R, b0, b1, bh, X, h, h1, h2, dh,
         [&](int i0, const float (&x)[4]) {
-          if (!ACTOR && on) {
+          if (!ACTOR && st) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) if (i0 + t < O) xt0[(size_t)(i0 + t) * m + row] = x[t];
+            for (int t = 0; t < 4; ++t) if (i0 + t < O) xt0[(unsigned)((i0 + t) * m + row)] = x[t];
           }
         },
         [&](int layer, f32x16 (&a)[2]) { store_units(layer == 1 ? xt1 : xt2, a); });
@@ -297,7 +442,7 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
 #pragma unroll
     for (int v = 0; v < 16; ++v) gout[v] = 0.f;
     if constexpr (!ACTOR) {
-      const float v_ = dh[0], ret = B.ret[s], vp = B.vpred[s];
+      const float v_ = dh[0], ret = sc_ret, vp = sc_vp;
       const float u = v_ - ret;
       float vl, gv;
       if (B.clipped_value) {                                       // ppo.py:61-66
@@ -310,7 +455,7 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
       } else { vl = 0.5f * u * u; gv = u; }                        // ppo.py:67-68
       const bool mine = on && h == 0;                              // unit 0 lives in lane half 0
       gout[0] = mine ? B.value_coef * gv * inv_m : 0.f;
-      if (mine) { gh[row] = gout[0]; loss_acc += vl; }
+      if (mine) { if (st) gh[row] = gout[0]; loss_acc += vl; }
     } else {
       float z[16], e[16], lp = 0.f;
 #pragma unroll
@@ -320,12 +465,12 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
         if ((8 * (v >> 2) + (v & 3)) < A && a < A) {
           const float ls = logstd[a];
           e[v] = expf(-ls);
-          z[v] = (B.actions[(size_t)s * A + a] - dh[v]) * e[v];
+          z[v] = (sc_act[v] - dh[v]) * e[v];
           lp += -0.5f * z[v] * z[v] - ls - HALF_LOG_2PI;
         }
       }
       lp += __shfl_xor(lp, 32, 64);
-      const float ratio = expf(lp - B.old_logp[s]), adv = B.adv[s];                                  // ppo.py:54-59
+      const float ratio = expf(lp - sc_olp), adv = sc_adv;                                  // ppo.py:54-59
       const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.0f - B.clip), 1.0f + B.clip) * adv;
       const float inside = (ratio >= 1.0f - B.clip && ratio <= 1.0f + B.clip) ? 1.0f : 0.0f;
       const float wsel = s1 < s2 ? 1.0f : (s1 > s2 ? inside : 0.5f * (1.0f + inside));
@@ -335,7 +480,7 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
         const int a = unit_of(0, v, h);
         if ((8 * (v >> 2) + (v & 3)) < A && a < A) {
           gout[v] = glp * z[v] * e[v];                               // d logp / d mean_a = z / sigma
-          if (on) gh[(size_t)a * m + row] = gout[v];
+          if (st) gh[(unsigned)(a * m + row)] = gout[v];
           gls_acc[v] += glp * (z[v] * z[v] - 1.0f);                  // d logp / d logstd_a = z^2 - 1
         }
       }
@@ -348,9 +493,13 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
 #pragma unroll
       for (int v = 0; v < 16; ++v) { d2[mt][v] = 0.f; d1[mt][v] = 0.f; }
 #pragma unroll
-    for (int v = 0; v < 4 * NR::QA; ++v) {
-      d2[0] = MFMA32(R.aht[0][v >> 2][v & 3], gout[v], d2[0]);
-      d2[1] = MFMA32(R.aht[1][v >> 2][v & 3], gout[v], d2[1]);
+    for (int q = 0; q < NR::QA; ++q) {
+      const float4 wa = R.AHT(0, q), wb = R.AHT(1, q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        d2[0] = MFMA32(comp4(wa, t), gout[4 * q + t], d2[0]);
+        d2[1] = MFMA32(comp4(wb, t), gout[4 * q + t], d2[1]);
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -360,9 +509,13 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        d1[0] = MFMA32(R.a1t[0][4 * mt + (v >> 2)][v & 3], d2[mt][v], d1[0]);
-        d1[1] = MFMA32(R.a1t[1][4 * mt + (v >> 2)][v & 3], d2[mt][v], d1[1]);
+      for (int qq = 0; qq < 4; ++qq) {
+        const float4 wa = R.A1T(0, 4 * mt + qq), wb = R.A1T(1, 4 * mt + qq);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          d1[0] = MFMA32(comp4(wa, t), d2[mt][4 * qq + t], d1[0]);
+          d1[1] = MFMA32(comp4(wb, t), d2[mt][4 * qq + t], d1[1]);
+        }
       }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -370,8 +523,8 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
       for (int v = 0; v < 16; ++v) d1[mt][v] *= 1.0f - h1[mt][v] * h1[mt][v];
     store_units(g1, d1);
   }
-  // this wavefront's row of partials: sums over its 64 rows
-  float* P_ = partials + (size_t)blockIdx.x * (3 + A);
+  // this wavefront's row of partials: sums over its 32 rows
+  float* P_ = partials + (size_t)(blockIdx.x * 4 + wave) * (3 + A);
   const float tot = wave_sum(loss_acc);
   if constexpr (!ACTOR) {
     if (l == 0) P_[0] = tot;
@@ -390,55 +543,154 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
   }
 }
 
+template <int O, int A> constexpr int stage1_lds_bytes() { return NetLds<O, A>::BYTES > NetLds<O, 1>::BYTES ? NetLds<O, A>::BYTES : NetLds<O, 1>::BYTES; }
 template <int O, int A>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256, 2)
 ppo_grad_stage1_mfma_kernel(CRITIC_ARGS, ACTOR_ARGS, const solorl_ppo_batch B, const solorl_ppo_stage1 W) {
-  if (blockIdx.y == 0) grad_net_mfma<O, A, false>(cw0, cb0, cw1, cb1, cwh, cbh, nullptr, B, W.xt0, W.c_xt1, W.c_xt2, W.c_g1, W.c_g2, W.c_gh, W.partials);
-  else grad_net_mfma<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, B, W.xt0, W.a_xt1, W.a_xt2, W.a_g1, W.a_g2, W.a_gh, W.partials);
+  extern __shared__ float4 stage1_image[];         // stage1_lds_bytes<O, A>() of dynamic LDS: 64-68 KB, two workgroups per CU
+  if (blockIdx.y == 0) grad_net_mfma<O, A, false>(cw0, cb0, cw1, cb1, cwh, cbh, nullptr, B, W.xt0, W.c_xt1, W.c_xt2, W.c_g1, W.c_g2, W.c_gh, W.partials, stage1_image);
+  else grad_net_mfma<O, A, true>(aw0, ab0, aw1, ab1, awh, abh, logstd, B, W.xt0, W.a_xt1, W.a_xt2, W.a_g1, W.a_g2, W.a_gh, W.partials, stage1_image);
 }
 
 // ---------------------------------------------------------------- stage 2 on MFMA: d W = G . X^T with the ROW index as K
-// One wavefront per (layer, 32-unit tile of G, 32-unit tile of X, chunk of MCHUNK rows).  Lane (c, h) reads 16 consecutive bytes
-// = rows r .. r + 3 of ITS unit's row of G (A operand) and of X (B operand), half h taking rows r0 + 4 h ..: four MFMA steps per
-// pair of loads, each step contracting one row from either half.  D register v of lane (c, h) is
-// d W[unit 32 mt + 8 (v >> 2) + 4 h + (v & 3)][input 32 nt + c]: stores are contiguous along the input index.
-constexpr int MCHUNK = 512;
-__global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Args S) {
-  int li = 0;
+// One wavefront per (layer, chunk of rows) computes ALL 32 x 32 tiles of the layer's product (2 x 3 for a hidden layer: 64 units x
+// 64 / 76 inputs) from ONE pass over the chunk's rows of G and X: every element of stage 1's arrays is read once.  (Round 3 ran one
+// wavefront per tile: G was read three times and X twice, 200 MB per mini-batch step at 4.6 TB/s = the kernel's 43 us.)
+// Lane (c, h) reads 16 consecutive bytes = rows r .. r + 3 of ITS unit's row of G (A operand, per unit tile) and of X (B operand, per
+// input tile), half h taking rows r0 + 4 h ..: each MFMA step contracts one row from either half.  D register v of lane (c, h) of
+// tile (mt, nt) is d W[unit 32 mt + 8 (v >> 2) + 4 h + (v & 3)][input 32 nt + c]: stores are contiguous along the input index.
+// The rows are cut into chunks, < 1024 wavefronts in all (stage2_plan); stage 3 adds the chunks' partial products in a fixed order.
+// One wavefront per SIMD at most (stage 2 holds 250-350 registers: occupancy 1): with 1026 wavefronts on 1024 SIMDs two of them waited
+// for a SIMD to come free and the kernel took two wavefront times (30 us) instead of one.
+constexpr int STAGE2_WAVES = 960;
+
+template <int NTM, int NTN>
+__device__ __forceinline__ void stage2_tiles(const LayerDesc& L, int m, int r0, int r1, float* __restrict__ out) {
+  const int l = threadIdx.x, c = l & 31, h = l >> 5;
+  const float* ga[NTM];
+  const float* xb[NTN];
+  bool va[NTM], vb[NTN];
 #pragma unroll
-  for (int i = 1; i < 6; ++i) if ((int)blockIdx.x >= S.L[i].tile0) li = i;
-  const LayerDesc& L = S.L[li];
-  const int ntn = (L.K1 + 31) / 32, ntm = (L.U + 31) / 32;
-  const int t = blockIdx.x - L.tile0, chunk = t / (ntm * ntn), tt = t % (ntm * ntn), mt = tt / ntn, nt = tt % ntn;
-  const int l = threadIdx.x, c = l & 31, h = l >> 5, m = S.m;
-  const int ua = 32 * mt + c, ub = 32 * nt + c;
-  const bool va = ua < L.U, vb = ub < L.K1;
-  const float* __restrict__ ga = L.g + (size_t)(va ? ua : 0) * m;
-  const float* __restrict__ xb = L.x + (size_t)(vb ? ub : 0) * m;
-  const int r0 = chunk * MCHUNK, r1 = min(r0 + MCHUNK, m);
-  f32x16 acc;
+  for (int mt = 0; mt < NTM; ++mt) { va[mt] = 32 * mt + c < L.U; ga[mt] = L.g + (size_t)(va[mt] ? 32 * mt + c : 0) * m; }
 #pragma unroll
-  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-  // (m is a multiple of 64: whole float4s, both halves always in range and on the same trip count.)  The loads of the next two
-  // steps are in flight while a step's four MFMAs run: a lone wavefront has nobody else to hide the L2 latency behind
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto lda = [&](int r) { return (va && r < r1) ? *reinterpret_cast<const float4*>(ga + r) : zero4; };
-  auto ldb = [&](int r) { return (vb && r < r1) ? *reinterpret_cast<const float4*>(xb + r) : zero4; };
+  for (int nt = 0; nt < NTN; ++nt) { vb[nt] = 32 * nt + c < L.K1 - 1; xb[nt] = L.x + (size_t)(vb[nt] ? 32 * nt + c : 0) * m; }
+  f32x16 acc[NTM][NTN];
+#pragma unroll
+  for (int mt = 0; mt < NTM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[mt][nt][v] = 0.f;
+  float bsum[NTM];                          // bias gradient = the row sum of G: the lane adds up ITS unit's operands (column K1 - 1 of the product, without a tile for it)
+#pragma unroll
+  for (int mt = 0; mt < NTM; ++mt) bsum[mt] = 0.f;
+  // m and the chunk are multiples of 16 rows: whole float4s, both halves on the same trip count, every load of an iteration in range --
+  // so the loads are UNCONDITIONAL (units past U / K1 read row 0 of the array and their results are never stored; the prefetch past the
+  // chunk's end re-reads its last rows).
+  struct Ops { float4 a[NTM][2], b[NTN][2]; };
+  auto load = [&](int r) {
+    Ops o;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int mt = 0; mt < NTM; ++mt) o.a[mt][j] = *reinterpret_cast<const float4*>(ga[mt] + r + 8 * j);
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt) o.b[nt][j] = *reinterpret_cast<const float4*>(xb[nt] + r + 8 * j);
+    }
+    return o;
+  };
+  // "pin": a compiler barrier that redefines the operands about to be used -- the loads written above it are ISSUED before it, the MFMAs
+  // that consume the operands come after it.  (Left alone the compiler sinks the prefetch in front of its uses: a full memory round
+  // trip per iteration with nothing in flight.)
+  auto pin4 = [](float4& f) { asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(f.z), "+v"(f.w) :: "memory"); };
+  auto pin = [&](Ops& o) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int mt = 0; mt < NTM; ++mt) pin4(o.a[mt][j]);
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt) pin4(o.b[nt][j]);
+    }
+  };
+  auto products = [&](const Ops& o) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mt = 0; mt < NTM; ++mt) {
+        bsum[mt] += (o.a[mt][j].x + o.a[mt][j].y) + (o.a[mt][j].z + o.a[mt][j].w);
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+          acc[mt][nt] = MFMA32(o.a[mt][j].x, o.b[nt][j].x, acc[mt][nt]); acc[mt][nt] = MFMA32(o.a[mt][j].y, o.b[nt][j].y, acc[mt][nt]);
+          acc[mt][nt] = MFMA32(o.a[mt][j].z, o.b[nt][j].z, acc[mt][nt]); acc[mt][nt] = MFMA32(o.a[mt][j].w, o.b[nt][j].w, acc[mt][nt]);
+        }
+      }
+  };
   int r = r0 + 4 * h;
-  float4 a0 = lda(r), b0 = ldb(r), a1 = lda(r + 8), b1 = ldb(r + 8);
+  const int rlast = r1 - 16 + 4 * h, nit = (r1 - r0) / 16;       // (nit: wave-uniform trip count)
+  // A ring of DEPTH + 1 operand sets (static indices: registers, no copies): the loads run DEPTH iterations ahead of their use.  An
+  // iteration's MFMAs take 0.43 us (a head: two tiles) to 1.28 us (six tiles) and loaded-memory latency is 2-3 us, so the depth goes with
+  // the tile count: 2 for six tiles, 3 for four, 6 for two (one iteration ahead at every size: 36 us for the kernel; two: 28 us, the heads'
+  // wavefronts being the stragglers).
+  constexpr int DEPTH = 12 / (NTM * NTN) < 2 ? 2 : (12 / (NTM * NTN) > 6 ? 6 : 12 / (NTM * NTN)), NS = DEPTH + 1;
+  Ops o[NS];
+  unrolled<DEPTH>([&](auto kc) { constexpr int k = decltype(kc)::value; o[k] = load(min(r + 16 * k, rlast)); });
+  int it = 0;
 #pragma unroll 1
-  for (; r < r1; r += 16) {
-    const float4 a2 = lda(r + 16), b2 = ldb(r + 16), a3 = lda(r + 24), b3 = ldb(r + 24);
-    acc = MFMA32(a0.x, b0.x, acc); acc = MFMA32(a0.y, b0.y, acc); acc = MFMA32(a0.z, b0.z, acc); acc = MFMA32(a0.w, b0.w, acc);
-    acc = MFMA32(a1.x, b1.x, acc); acc = MFMA32(a1.y, b1.y, acc); acc = MFMA32(a1.z, b1.z, acc); acc = MFMA32(a1.w, b1.w, acc);
-    a0 = a2; b0 = b2; a1 = a3; b1 = b3;
+  for (; it + NS <= nit; it += NS, r += 16 * NS) {
+    unrolled<NS>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      o[(k + DEPTH) % NS] = load(min(r + 16 * (k + DEPTH), rlast));
+      pin(o[k]); products(o[k]);
+    });
   }
-  float* out = S.scratch + (size_t)chunk * S.total + L.off;
+  unrolled<DEPTH>([&](auto kc) { constexpr int k = decltype(kc)::value; if (it + k < nit) { pin(o[k]); products(o[k]); } });
 #pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    const int u = 32 * mt + 8 * (v >> 2) + 4 * h + (v & 3);
-    if (u < L.U && vb) out[u * L.K1 + ub] = acc[v];
+  for (int mt = 0; mt < NTM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int u = 32 * mt + 8 * (v >> 2) + 4 * h + (v & 3);
+        if (u < L.U && vb[nt]) out[u * L.K1 + 32 * nt + c] = acc[mt][nt][v];
+      }
+#pragma unroll
+  for (int mt = 0; mt < NTM; ++mt) {
+    const float b = bsum[mt] + __shfl_xor(bsum[mt], 32, 64);          // the unit's other rows were summed by the other lane half
+    if (h == 0 && va[mt]) out[(32 * mt + c) * L.K1 + L.K1 - 1] = b;
   }
+}
+
+__global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Args S) {
+  LayerDesc L = S.L[0];                  // (wave-uniform selects: a dynamic index into the argument struct would be served from scratch)
+#pragma unroll
+  for (int i = 1; i < 6; ++i) if ((int)blockIdx.x >= S.L[i].wave0) L = S.L[i];
+  const int chunk = blockIdx.x - L.wave0;
+  const int ntn = (L.K1 - 1 + 31) / 32, ntm = (L.U + 31) / 32;          // tiles over the K1 - 1 inputs; the bias column is a row sum
+  const int r0 = chunk * L.mchunk, r1 = min(r0 + L.mchunk, S.m);
+  float* out = S.scratch + L.sbase + (size_t)chunk * L.U * L.K1;
+  if (ntm == 2) {
+    if (ntn == 3) stage2_tiles<2, 3>(L, S.m, r0, r1, out); else if (ntn == 2) stage2_tiles<2, 2>(L, S.m, r0, r1, out); else stage2_tiles<2, 1>(L, S.m, r0, r1, out);
+  } else {
+    if (ntn == 3) stage2_tiles<1, 3>(L, S.m, r0, r1, out); else if (ntn == 2) stage2_tiles<1, 2>(L, S.m, r0, r1, out); else stage2_tiles<1, 1>(L, S.m, r0, r1, out);
+  }
+}
+
+// The chunking of a mini-batch of m rows: every layer gets wavefronts in proportion to its tile count (6 : 4 : 2 for obs -> 64 -> 64 ->
+// head at 76 inputs), at most STAGE2_WAVES in all, so that all wavefronts carry the same number of MFMAs.  Chunks are multiples of 16 rows.
+struct Stage2Plan { int nchunks[6], mchunk[6], wave0[6], sbase[6], off[6], nwaves, total, scratch; };
+inline Stage2Plan stage2_plan(int O, int A, int m) {
+  const int U[6] = {H, H, 1, H, H, A}, K1[6] = {O + 1, H + 1, H + 1, O + 1, H + 1, H + 1};
+  Stage2Plan P{};
+  int tiles[6], all = 0;
+  for (int i = 0; i < 6; ++i) { tiles[i] = ((U[i] + 31) / 32) * ((K1[i] - 1 + 31) / 32); all += tiles[i]; }
+  for (int i = 0; i < 6; ++i) {
+    const int want = STAGE2_WAVES * tiles[i] / all > 0 ? STAGE2_WAVES * tiles[i] / all : 1;       // wavefronts for this layer (rounded DOWN, chunks rounded up)
+    const int mc = (((m + want - 1) / want + 15) / 16) * 16;
+    P.mchunk[i] = mc; P.nchunks[i] = (m + mc - 1) / mc;
+    P.wave0[i] = P.nwaves; P.sbase[i] = P.scratch; P.off[i] = P.total;
+    P.nwaves += P.nchunks[i]; P.scratch += P.nchunks[i] * U[i] * K1[i]; P.total += U[i] * K1[i];
+  }
+  return P;
 }
 
 // ---------------------------------------------------------------- norm clip + Adam over all 13 parameter tensors, one workgroup
@@ -448,42 +700,99 @@ __global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Ar
 struct AdamSeg { float* p; const float* g; int n, off; };
 struct AdamArgs { AdamSeg seg[13]; int total; float* m; float* v; float* step; const float* lr; float b1, b2, eps, wd, max_norm, gscale;
                   long long* offset; long long inc; };
+
+
+// The tensor sizes are compile-time (dispatch_dims), so the walk over the 13 tensors is unrolled with STATIC indices into the argument
+// struct (round 3's attempt indexed it dynamically and the compiler served it from scratch: 31 us; the tensor-by-tensor loops it
+// fell back to waited for one L2 round trip per tensor and pass: 22 us).  A thread owns element tid + 1024 j of tensor s for every
+// (s, j) -- 27-29 slots: every gradient is loaded ONCE, all loads of a phase are in flight together, the gradients stay in
+// registers between the norm and the update.
+template <int O, int A> struct AdamDims {
+  static constexpr int n(int s) { constexpr int N[13] = {H * O, H, H * H, H, H, 1, H * O, H, H * H, H, A * H, A, A}; return N[s]; }
+  static constexpr int cnt(int s) { return (n(s) + 1023) / 1024; }
+  static constexpr int base(int s) { int b = 0; for (int i = 0; i < s; ++i) b += cnt(i); return b; }
+  static constexpr int SLOTS = base(13);
+  static constexpr int seg(int k) { int s = 0; while (base(s + 1) <= k) ++s; return s; }     // slot k = element tid + 1024 j(k) of tensor seg(k)
+  static constexpr int j(int k) { return k - base(seg(k)); }
+  static constexpr int GROUP = 3, NGROUPS = (SLOTS + GROUP - 1) / GROUP, AHEAD = 2;     // update phase: groups of three slots, two groups in flight ahead of the
+                                                                                        // one being updated (128 registers at 1024 threads; ONE group ahead: a memory round trip per group, 12 us)
+};
+template <int O, int A>
 __global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(const AdamArgs K) {
-  // (a variant with one flat element per (thread, slot) and all loads of a pass issued together was slower, 31 vs 22 us: finding
-  // an element's tensor means indexing the argument struct dynamically, which the compiler serves from scratch)
+  using D = AdamDims<O, A>;
   __shared__ float red[16];
-  __shared__ float coef_s;
-  const int tid = threadIdx.x;
-  float ss = 0.f;
-#pragma unroll 1
-  for (int s = 0; s < 13; ++s)
-    for (int i = tid; i < K.seg[s].n; i += 1024) { const float g = K.seg[s].g[i] * K.gscale; ss = fmaf(g, g, ss); }
+  __shared__ float coef_s, step_size_s, inv_sqrt_bc2_s;
+  const unsigned tid = threadIdx.x;        // (unsigned element offsets: scalar base + 32-bit vector offset addressing, no 64-bit address registers)
+  float g[D::SLOTS], ss = 0.f;
+  unrolled<D::SLOTS>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, s = D::seg(k), jj = D::j(k), nn = D::n(s);      // (constexpr variables: forced constant evaluation)
+    const unsigned i = tid + 1024u * jj;
+    g[k] = K.seg[s].g[min(i, (unsigned)(nn - 1))];          // (clamped and UNCONDITIONAL: all loads are issued here ...
+  });
+  asm volatile("" ::: "memory");
+  unrolled<D::SLOTS>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, s = D::seg(k), jj = D::j(k), nn = D::n(s);
+    asm volatile("" : "+v"(g[k]));            //  ... and pinned here: left alone the compiler sinks each load into the branch of its select
+    g[k] = tid + 1024u * jj < nn ? g[k] * K.gscale : 0.f;     //  and waits for it there, one memory round trip per partly filled slot: 12 us)
+  });                                         // gscale: 1 / world after a SUMMED gradient all-reduce (the mean's scale, fused)
+  struct PMV { float p[D::GROUP], m[D::GROUP], v[D::GROUP]; };
+  auto load_group = [&](auto gc) {
+    constexpr int k0 = decltype(gc)::value * D::GROUP;
+    PMV r;
+    unrolled<D::GROUP>([&](auto qc) {
+      constexpr int q = decltype(qc)::value, k = k0 + q;
+      if constexpr (k < D::SLOTS) {
+        constexpr int s = D::seg(k), jj = D::j(k), nn = D::n(s);
+        const unsigned i = tid + 1024u * jj;
+        const unsigned ic = min(i, (unsigned)(nn - 1));
+        r.p[q] = K.seg[s].p[ic]; r.m[q] = K.m[(unsigned)K.seg[s].off + ic]; r.v[q] = K.v[(unsigned)K.seg[s].off + ic];
+      }
+    });
+    return r;
+  };
+  PMV ring[D::AHEAD + 1];
+  unrolled<D::AHEAD>([&](auto gc) { if constexpr (decltype(gc)::value < D::NGROUPS) ring[decltype(gc)::value] = load_group(gc); });   // (do not depend on the norm: in flight across the reduction)
+#pragma unroll
+  for (int k = 0; k < D::SLOTS; ++k) ss = fmaf(g[k], g[k], ss);
   ss = wave_sum(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
+  const float step = *K.step + 1.0f, lr = *K.lr;
   __syncthreads();
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < 16; ++w) t += red[w];
     coef_s = K.max_norm > 0.f ? fminf(1.0f, K.max_norm / (sqrtf(t) + 1e-6f)) : 1.0f;      // clip_coef clamped to 1
+    // (one thread: two powf are ~300 instructions, and the whole launch is one CU's instruction issue: 16 wavefronts on 4 SIMDs)
+    const float bc1 = 1.0f - powf(K.b1, step), bc2 = 1.0f - powf(K.b2, step);
+    step_size_s = lr / bc1; inv_sqrt_bc2_s = 1.0f / sqrtf(bc2);
   }
   __syncthreads();
-  const float coef = coef_s, step = *K.step + 1.0f, lr = *K.lr;
-  const float bc1 = 1.0f - powf(K.b1, step), bc2 = 1.0f - powf(K.b2, step);
-  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
-#pragma unroll 1
-  for (int s = 0; s < 13; ++s) {
-    const AdamSeg& S = K.seg[s];
-    for (int i = tid; i < S.n; i += 1024) {
-      float p = S.p[i], g = S.g[i] * K.gscale * coef;        // gscale: 1 / world after a SUMMED gradient all-reduce (the mean's scale, fused)
-      if (K.wd != 0.f) g = fmaf(K.wd, p, g);
-      const int j = S.off + i;
-      const float m = K.m[j] + (1.0f - K.b1) * (g - K.m[j]);                 // exp_avg.lerp_(grad, 1 - beta1)
-      const float v = K.b2 * K.v[j] + (1.0f - K.b2) * g * g;
-      K.m[j] = m; K.v[j] = v;
-      S.p[i] = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + K.eps));
-    }
-  }
-  __syncthreads();                                                            // everyone has read *K.step
+  const float coef = coef_s, step_size = step_size_s, inv_sqrt_bc2 = inv_sqrt_bc2_s;
+  unrolled<D::NGROUPS>([&](auto gc) {
+    constexpr int gi = decltype(gc)::value, k0 = gi * D::GROUP;
+    if constexpr (gi + D::AHEAD < D::NGROUPS) ring[(gi + D::AHEAD) % (D::AHEAD + 1)] = load_group(std::integral_constant<int, gi + D::AHEAD>{});
+    PMV& cur = ring[gi % (D::AHEAD + 1)];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < D::GROUP; ++q) asm volatile("" : "+v"(cur.p[q]), "+v"(cur.m[q]), "+v"(cur.v[q]));       // (as above: the loads stay where they were issued)
+    unrolled<D::GROUP>([&](auto qc) {
+      constexpr int q = decltype(qc)::value, k = k0 + q;
+      if constexpr (k < D::SLOTS) {
+        constexpr int s = D::seg(k), jj = D::j(k), nn = D::n(s);
+        const unsigned i = tid + 1024u * jj;
+        if (i < nn) {
+          float gg = g[k] * coef;
+          if (K.wd != 0.f) gg = fmaf(K.wd, cur.p[q], gg);
+          const float mn = cur.m[q] + (1.0f - K.b1) * (gg - cur.m[q]);                 // exp_avg.lerp_(grad, 1 - beta1)
+          const float vn = K.b2 * cur.v[q] + (1.0f - K.b2) * gg * gg;
+          K.m[(unsigned)K.seg[s].off + i] = mn; K.v[(unsigned)K.seg[s].off + i] = vn;
+          // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrt and division (~25 instructions per element)
+          K.seg[s].p[i] = cur.p[q] - step_size * (mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vn) * inv_sqrt_bc2 + K.eps));
+        }
+      }
+    });
+  });
+  // (every thread read *K.step before the first barrier)
   if (tid == 0) { *K.step = step; if (K.offset) *K.offset += K.inc; }
 }
 
@@ -536,6 +845,8 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
                            void* stream) {
   if (int rc = check_policy(p, device_id)) return rc;
   if (!batch || !work || batch->m < 1) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: null argument or m < 1");
+  if ((long long)batch->m * (p->obs_dim > H ? p->obs_dim : H) >= (1LL << 31))
+    return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: mini-batch too large (the [unit][row] arrays are indexed with 32 bits)");
   const void* ptrs[] = {batch->obs, batch->actions, batch->old_logp, batch->adv, batch->vpred, batch->ret, batch->perm, batch->offset,
                         work->xt0, work->c_xt1, work->c_xt2, work->c_g1, work->c_g2, work->c_gh, work->a_xt1, work->a_xt2, work->a_g1,
                         work->a_g2, work->a_gh, work->partials};
@@ -546,12 +857,21 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
   const solorl_ppo_stage1 W = *work;
   return dispatch_dims(P.obs_dim, P.act_dim, [&](auto oc, auto ac) {
     constexpr int O = decltype(oc)::value, A = decltype(ac)::value;
-    hipLaunchKernelGGL((ppo_grad_stage1_mfma_kernel<O, A>), dim3((B.m + 63) / 64, 2), dim3(64), 0, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, B, W);
+    constexpr int LDS = stage1_lds_bytes<O, A>();
+    static bool lds_ok = false;              // (more than the 64 KB a kernel gets by default: raised once per instantiation)
+    if (!lds_ok) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_grad_stage1_mfma_kernel<O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage1_mfma_kernel: cannot raise the dynamic LDS limit");
+      lds_ok = true;
+    }
+    hipLaunchKernelGGL((ppo_grad_stage1_mfma_kernel<O, A>), dim3((B.m + 127) / 128, 2), dim3(256), LDS, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, B, W);
     return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage1_mfma_kernel launch");
   });
 }
 
 int solorl_ppo_grad_count(int obs_dim, int act_dim) { return 2 * H * (obs_dim + 1) + 2 * H * (H + 1) + (H + 1) + act_dim * (H + 1); }
+
+int solorl_ppo_scratch_count(int obs_dim, int act_dim, int m) { return m < 1 ? 0 : stage2_plan(obs_dim, act_dim, m).scratch; }
 
 int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage1* work, int m, const solorl_ppo_grads* out, int device_id,
                            void* stream) {
@@ -569,18 +889,16 @@ int solorl_ppo_grad_stage2(const solorl_policy_params* p, const solorl_ppo_stage
       {work->c_gh, work->c_xt2, out->critic_w2, out->critic_b2, 1, H + 1, 0, 0}, {work->a_g1, work->xt0, out->actor_w0, out->actor_b0, H, O + 1, 0, 0},
       {work->a_g2, work->a_xt1, out->actor_w1, out->actor_b1, H, H + 1, 0, 0}, {work->a_gh, work->a_xt2, out->mean_w, out->mean_b, A, H + 1, 0, 0}};
   if (m % 64 != 0) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage2: m must be a multiple of 64 rows");
-  S.m = m; S.nchunks = (m + MCHUNK - 1) / MCHUNK; S.scratch = out->scratch;
-  int off = 0, tile = 0;
+  const Stage2Plan plan = stage2_plan(O, A, m);
+  S.m = m; S.scratch = out->scratch; S.total = plan.total; S.nwaves = plan.nwaves; S.reserved = 0;
   for (int i = 0; i < 6; ++i) {
-    S.L[i] = L[i]; S.L[i].off = off; S.L[i].tile0 = tile;
-    off += L[i].U * L[i].K1;
-    tile += ((L[i].U + 31) / 32) * ((L[i].K1 + 31) / 32) * S.nchunks;
+    S.L[i] = L[i]; S.L[i].off = plan.off[i]; S.L[i].nchunks = plan.nchunks[i]; S.L[i].mchunk = plan.mchunk[i]; S.L[i].wave0 = plan.wave0[i];
+    S.L[i].sbase = plan.sbase[i];
   }
-  S.total = off; S.ntiles = tile;
-  T.partials = work->partials; T.nwaves = (m + 63) / 64; T.A = A; T.logstd = p->logstd; T.logstd_grad = out->logstd;
+  T.partials = work->partials; T.nwaves = (m + 31) / 32; T.A = A; T.logstd = p->logstd; T.logstd_grad = out->logstd;
   T.loss_sums = out->loss_sums; T.logstd_sum = out->logstd_sum; T.entropy_coef = out->entropy_coef;
-  hipLaunchKernelGGL(ppo_grad_stage2_mfma_kernel, dim3(S.ntiles), dim3(64), 0, (hipStream_t)stream, S);
-  hipLaunchKernelGGL(ppo_grad_stage3_kernel, dim3((S.total + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, T);
+  hipLaunchKernelGGL(ppo_grad_stage2_mfma_kernel, dim3(S.nwaves), dim3(64), 0, (hipStream_t)stream, S);
+  hipLaunchKernelGGL(ppo_grad_stage3_kernel, dim3((S.total + 15) / 16 + 3 + A), dim3(256), 0, (hipStream_t)stream, T);
   return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage2/3 launch");
 }
 
@@ -604,8 +922,10 @@ int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* 
   K.b1 = a->beta1; K.b2 = a->beta2; K.eps = a->eps; K.wd = a->weight_decay; K.max_norm = a->max_grad_norm;
   K.gscale = a->grad_scale > 0.f ? a->grad_scale : 1.0f;
   K.offset = reinterpret_cast<long long*>(a->offset); K.inc = a->offset_increment;
-  hipLaunchKernelGGL(ppo_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, K);
-  return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_clip_adam_kernel launch");
+  return dispatch_dims(O, A, [&](auto oc, auto ac) {
+    hipLaunchKernelGGL((ppo_clip_adam_kernel<decltype(oc)::value, decltype(ac)::value>), dim3(1), dim3(1024), 0, (hipStream_t)stream, K);
+    return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_clip_adam_kernel launch");
+  });
 }
 
 }  // extern "C"

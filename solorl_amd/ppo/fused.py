@@ -139,13 +139,10 @@ class MiniBatchGrad:
         assert self._keep[0].data_ptr() == storage.obs.data_ptr() and perm.dtype == torch.long and offset.dtype == torch.long
         B.m, B.clipped_value, B.clip, B.value_coef = m, int(bool(clipped_value)), float(clip), float(value_coef)
 
-        def xt(units):                       # [units + 1][m]: the last row stays 1 -> the bias gradient is the product's last column
-            t = torch.zeros(units + 1, m, device=dev)
-            t[units].fill_(1.0)
-            return t
         z = lambda u: torch.zeros(u, m, device=dev)
+        xt = z                                # (activations [units][m]; the bias gradients are row sums of g, no row of ones)
         self.buf = dict(xt0=xt(O), c_xt1=xt(H), c_xt2=xt(H), c_g1=z(H), c_g2=z(H), c_gh=z(1), a_xt1=xt(H), a_xt2=xt(H), a_g1=z(H), a_g2=z(H),
-                        a_gh=z(A), partials=torch.zeros((m + 63) // 64, 3 + A, device=dev))
+                        a_gh=z(A), partials=torch.zeros((m + 31) // 32, 3 + A, device=dev))
         W = self.W = _native.PpoStage1()
         for k, t in self.buf.items():
             setattr(W, k, t.data_ptr())
@@ -153,7 +150,7 @@ class MiniBatchGrad:
         self.psum = torch.zeros(3 + A, device=dev)          # running sums of the partials over the steps of an update
         self.ent = torch.zeros(1, device=dev)               # running sum of sum_a logstd_a
         L = _native.lib()
-        self.scratch = torch.zeros(((m + 511) // 512) * L.solorl_ppo_grad_count(O, A), device=dev)
+        self.scratch = torch.zeros(L.solorl_ppo_scratch_count(O, A, m), device=dev)
         G = self.G = _native.PpoGrads()
         grads = {"critic_w0": b.critic[0].weight, "critic_b0": b.critic[0].bias, "critic_w1": b.critic[2].weight, "critic_b1": b.critic[2].bias,
                  "critic_w2": b.critic[4].weight, "critic_b2": b.critic[4].bias, "actor_w0": b.features[0].weight, "actor_b0": b.features[0].bias,
