@@ -255,10 +255,11 @@ typedef struct solorl_ppo_batch {
   int clipped_value;           /* ppo.py:61 use_clipped_value_loss */
   float clip, value_coef;      /* ppo.py:56 clip_param; the value-loss coefficient is folded into the critic's gradient */
 } solorl_ppo_batch;
-/* Outputs, all [unit][m] (row index fastest): xt0 = gathered observations [obs_dim][m]; per net (c_ critic, a_ actor) the hidden
- * activations xt1, xt2 [64][m], the pre-activation gradients g1, g2 [64][m] and the head-output gradient gh ([1][m] / [A][m]).
- * Weight gradients are then G^T X products over the rows:  d W0 = g1 xt0^T, d W1 = g2 xt1^T, d Whead = gh xt2^T, biases = row
- * sums of g.  partials [ceil(m/32)][3 + A]: per 32 rows (sum value loss, sum action loss, rows, sum d action-loss / d logstd_a; ABI 5:
+/* Outputs (m a multiple of 32), each units x m floats laid out [tile = row / 32][unit][row % 32] -- a tile of 32 rows is one contiguous
+ * block (ABI 5; it was [unit][m]): xt0 = gathered observations (obs_dim units); per net (c_ critic, a_ actor) the hidden activations
+ * xt1, xt2 (64 units), the pre-activation gradients g1, g2 (64 units) and the head-output gradient gh (1 / A units).
+ * Weight gradients are then G X^T products over the rows:  d W0 = g1 xt0^T, d W1 = g2 xt1^T, d Whead = gh xt2^T, biases = row
+ * sums of g.  partials [m / 32][3 + A]: per 32 rows (sum value loss, sum action loss, rows, sum d action-loss / d logstd_a; ABI 5:
  * one row per 32 samples, it was 64);
  * the entropy term of ppo.py:74 does not depend on the samples and is left to the caller. */
 typedef struct solorl_ppo_stage1 {

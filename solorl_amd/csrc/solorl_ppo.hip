@@ -139,9 +139,10 @@ __global__ void __launch_bounds__(256) ppo_grad_stage3_kernel(const Stage3Args T
 // so a lane's 16 results belong to ITS row c and to the units {8 q + 4 h + t}.  A step of the NEXT layer contracts over two
 // units, one from each lane half; taking them as (8 q + t) from half 0 and (8 q + 4 + t) from half 1 makes the next layer's B
 // operand for step (q, t) exactly register v = 4 q' + t of the previous D (q' = q mod 4, tile mt = q / 4): activations never
-// leave their registers between layers, forward or backward, and there is no LDS in these kernels.  The matching A element
-// is W[unit 32 mt + c][input 8 q + 4 h + t]: a lane reads 16 consecutive bytes of one weight row per q -- all weights of a net
-// (forward and transposed, 256 VGPRs) are loaded once per wavefront and stay in registers while it walks over its row tiles.
+// leave their registers between layers, forward or backward.  The matching A element is W[unit 32 mt + c][input 8 q + 4 h + t]: a
+// lane reads 16 consecutive bytes of one weight row per q.  The act kernel keeps a net's forward weights in registers (NetRegs, 170
+// VGPRs, one wavefront per 32 rows); stage 1 needs the transposed weights too and keeps the per-lane operand image in LDS instead
+// (NetLds: one copy per workgroup of four wavefronts, ds_read_b128 per four MFMAs).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef SOLO_PPO_NOMFMA      // dev experiment (tools/dev/build_ppo_variant.py): what the kernels cost without their matrix products
 #define MFMA32(a, b, c) (c)
@@ -380,7 +381,7 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
   const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, c = l & 31, h = l >> 5, m = B.m;
   // the tile's row: its index through the permutation, then its observation and its scalars -- issued BEFORE the image is filled, so that
   // the two dependent memory round trips run under the fill instead of after it
-  const int tile0 = (blockIdx.x * 4 + wave) * 32;
+  const int tile = blockIdx.x * 4 + wave, tile0 = tile * 32;
   const int row = tile0 + c;
   const bool on = row < m;
   const int r = on ? row : m - 1;
@@ -426,14 +427,14 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int v = 0; v < 16; ++v) arr[(unsigned)(unit_of(mt, v, h) * m + row)] = a[mt][v];     // (32-bit element offsets: the arrays are < 2^31 elements, checked by the host)
+          for (int v = 0; v < 16; ++v) arr[(unsigned)((tile * H + unit_of(mt, v, h)) * 32 + c)] = a[mt][v];     // [tile][unit][32 rows] (32-bit element offsets: checked by the host)
       }
     };
     mfma_forward<O, NOUT>(R, b0, b1, bh, X, h, h1, h2, dh,
         [&](int i0, const float (&x)[4]) {
           if (!ACTOR && st) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) if (i0 + t < O) xt0[(unsigned)((i0 + t) * m + row)] = x[t];
+            for (int t = 0; t < 4; ++t) if (i0 + t < O) xt0[(unsigned)((tile * O + i0 + t) * 32 + c)] = x[t];
           }
         },
         [&](int layer, f32x16 (&a)[2]) { store_units(layer == 1 ? xt1 : xt2, a); });
@@ -480,7 +481,7 @@ __device__ __forceinline__ void grad_net_mfma(NET_ARGS, const float* __restrict_
         const int a = unit_of(0, v, h);
         if ((8 * (v >> 2) + (v & 3)) < A && a < A) {
           gout[v] = glp * z[v] * e[v];                               // d logp / d mean_a = z / sigma
-          if (st) gh[(unsigned)(a * m + row)] = gout[v];
+          if (st) gh[(unsigned)((tile * A + a) * 32 + c)] = gout[v];
           gls_acc[v] += glp * (z[v] * z[v] - 1.0f);                  // d logp / d logstd_a = z^2 - 1
         }
       }
@@ -556,8 +557,8 @@ ppo_grad_stage1_mfma_kernel(CRITIC_ARGS, ACTOR_ARGS, const solorl_ppo_batch B, c
 // One wavefront per (layer, chunk of rows) computes ALL 32 x 32 tiles of the layer's product (2 x 3 for a hidden layer: 64 units x
 // 64 / 76 inputs) from ONE pass over the chunk's rows of G and X: every element of stage 1's arrays is read once.  (Round 3 ran one
 // wavefront per tile: G was read three times and X twice, 200 MB per mini-batch step at 4.6 TB/s = the kernel's 43 us.)
-// Lane (c, h) reads 16 consecutive bytes = rows r .. r + 3 of ITS unit's row of G (A operand, per unit tile) and of X (B operand, per
-// input tile), half h taking rows r0 + 4 h ..: each MFMA step contracts one row from either half.  D register v of lane (c, h) of
+// Lane (c, h) reads rows of ITS unit's row of G (A operand, per unit tile) and of X (B operand, per input tile), each MFMA step
+// contracts one row from either lane half (stage2_tiles has the row assignment).  D register v of lane (c, h) of
 // tile (mt, nt) is d W[unit 32 mt + 8 (v >> 2) + 4 h + (v & 3)][input 32 nt + c]: stores are contiguous along the input index.
 // The rows are cut into chunks, < 1024 wavefronts in all (stage2_plan); stage 3 adds the chunks' partial products in a fixed order.
 // One wavefront per SIMD at most (stage 2 holds 250-350 registers: occupancy 1): with 1026 wavefronts on 1024 SIMDs two of them waited
@@ -571,9 +572,10 @@ __device__ __forceinline__ void stage2_tiles(const LayerDesc& L, int m, int r0, 
   const float* xb[NTN];
   bool va[NTM], vb[NTN];
 #pragma unroll
-  for (int mt = 0; mt < NTM; ++mt) { va[mt] = 32 * mt + c < L.U; ga[mt] = L.g + (size_t)(va[mt] ? 32 * mt + c : 0) * m; }
+  for (int mt = 0; mt < NTM; ++mt) { va[mt] = 32 * mt + c < L.U; ga[mt] = L.g + (va[mt] ? 32 * mt + c : 0) * 32 + 4 * h; }
 #pragma unroll
-  for (int nt = 0; nt < NTN; ++nt) { vb[nt] = 32 * nt + c < L.K1 - 1; xb[nt] = L.x + (size_t)(vb[nt] ? 32 * nt + c : 0) * m; }
+  for (int nt = 0; nt < NTN; ++nt) { vb[nt] = 32 * nt + c < L.K1 - 1; xb[nt] = L.x + (vb[nt] ? 32 * nt + c : 0) * 32 + 4 * h; }
+  const unsigned gstep = (unsigned)L.U * 32u, xstep = (unsigned)(L.K1 - 1) * 32u;       // elements per tile of G / X
   f32x16 acc[NTM][NTN];
 #pragma unroll
   for (int mt = 0; mt < NTM; ++mt)
@@ -584,18 +586,24 @@ __device__ __forceinline__ void stage2_tiles(const LayerDesc& L, int m, int r0, 
   float bsum[NTM];                          // bias gradient = the row sum of G: the lane adds up ITS unit's operands (column K1 - 1 of the product, without a tile for it)
 #pragma unroll
   for (int mt = 0; mt < NTM; ++mt) bsum[mt] = 0.f;
-  // m and the chunk are multiples of 16 rows: whole float4s, both halves on the same trip count, every load of an iteration in range --
-  // so the loads are UNCONDITIONAL (units past U / K1 read row 0 of the array and their results are never stored; the prefetch past the
-  // chunk's end re-reads its last rows).
-  struct Ops { float4 a[NTM][2], b[NTN][2]; };
-  auto load = [&](int r) {
+  // Stage 1 writes its arrays [tile of 32 rows][unit][32 rows]: a wavefront's tile is one contiguous block per array (8 KB for 64 units),
+  // and so is what a stage-2 wavefront reads.  An iteration contracts HALF a tile (16 rows): lane (c, h) reads rows 4 h .. 4 h + 3 and
+  // 8 + 4 h .. 8 + 4 h + 3 of its unit (two float4); MFMA step s pairs a row of lane half 0 with one of half 1 -- any pairing is a valid
+  // order of the sum.  Loads are UNCONDITIONAL: units past U / K1 read unit 0 and their results are never stored; the prefetch past the
+  // chunk's end re-reads its last rows.
+  // Measured: with the MFMAs taken out the kernel takes 22 of its 27 us, whatever the layout ([unit][m] arrays, 64 consecutive bytes per
+  // lane, this blocked one): it moves 80 MB at ~3.7 TB/s and that is its bound; what the variants differ in is how finely the pipeline
+  // below is cut (whole-tile iterations, one ahead: 31 us).
+  constexpr int NJ = 2;
+  struct Ops { float4 a[NTM][NJ], b[NTN][NJ]; };
+  auto load = [&](int r) {          // r: half-tile index (16 rows)
     Ops o;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int mt = 0; mt < NTM; ++mt) o.a[mt][j] = *reinterpret_cast<const float4*>(ga[mt] + r + 8 * j);
+      for (int mt = 0; mt < NTM; ++mt) o.a[mt][j] = *reinterpret_cast<const float4*>(ga[mt] + (unsigned)(r >> 1) * gstep + 16 * (r & 1) + 8 * j);
 #pragma unroll
-      for (int nt = 0; nt < NTN; ++nt) o.b[nt][j] = *reinterpret_cast<const float4*>(xb[nt] + r + 8 * j);
+      for (int nt = 0; nt < NTN; ++nt) o.b[nt][j] = *reinterpret_cast<const float4*>(xb[nt] + (unsigned)(r >> 1) * xstep + 16 * (r & 1) + 8 * j);
     }
     return o;
   };
@@ -605,7 +613,7 @@ __device__ __forceinline__ void stage2_tiles(const LayerDesc& L, int m, int r0, 
   auto pin4 = [](float4& f) { asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(f.z), "+v"(f.w) :: "memory"); };
   auto pin = [&](Ops& o) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
       for (int mt = 0; mt < NTM; ++mt) pin4(o.a[mt][j]);
 #pragma unroll
@@ -614,7 +622,7 @@ __device__ __forceinline__ void stage2_tiles(const LayerDesc& L, int m, int r0, 
   };
   auto products = [&](const Ops& o) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int mt = 0; mt < NTM; ++mt) {
         bsum[mt] += (o.a[mt][j].x + o.a[mt][j].y) + (o.a[mt][j].z + o.a[mt][j].w);
@@ -625,21 +633,20 @@ __device__ __forceinline__ void stage2_tiles(const LayerDesc& L, int m, int r0, 
         }
       }
   };
-  int r = r0 + 4 * h;
-  const int rlast = r1 - 16 + 4 * h, nit = (r1 - r0) / 16;       // (nit: wave-uniform trip count)
+  int r = r0 / 16;                                                // half tiles r0 / 16 .. r1 / 16 - 1
+  const int rlast = r1 / 16 - 1, nit = (r1 - r0) / 16;
   // A ring of DEPTH + 1 operand sets (static indices: registers, no copies): the loads run DEPTH iterations ahead of their use.  An
-  // iteration's MFMAs take 0.43 us (a head: two tiles) to 1.28 us (six tiles) and loaded-memory latency is 2-3 us, so the depth goes with
-  // the tile count: 2 for six tiles, 3 for four, 6 for two (one iteration ahead at every size: 36 us for the kernel; two: 28 us, the heads'
-  // wavefronts being the stragglers).
+  // iteration's MFMAs take 0.43 us (a head: two tiles) to 1.28 us (six tiles) against 2-3 us of loaded-memory latency, so the depth goes
+  // with the tile count: 2 for six tiles, 3 for four, 6 for two.
   constexpr int DEPTH = 12 / (NTM * NTN) < 2 ? 2 : (12 / (NTM * NTN) > 6 ? 6 : 12 / (NTM * NTN)), NS = DEPTH + 1;
   Ops o[NS];
-  unrolled<DEPTH>([&](auto kc) { constexpr int k = decltype(kc)::value; o[k] = load(min(r + 16 * k, rlast)); });
+  unrolled<DEPTH>([&](auto kc) { constexpr int k = decltype(kc)::value; o[k] = load(min(r + k, rlast)); });
   int it = 0;
 #pragma unroll 1
-  for (; it + NS <= nit; it += NS, r += 16 * NS) {
+  for (; it + NS <= nit; it += NS, r += NS) {
     unrolled<NS>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      o[(k + DEPTH) % NS] = load(min(r + 16 * (k + DEPTH), rlast));
+      o[(k + DEPTH) % NS] = load(min(r + k + DEPTH, rlast));
       pin(o[k]); products(o[k]);
     });
   }
@@ -676,7 +683,7 @@ __global__ void __launch_bounds__(64) ppo_grad_stage2_mfma_kernel(const Stage2Ar
 }
 
 // The chunking of a mini-batch of m rows: every layer gets wavefronts in proportion to its tile count (6 : 4 : 2 for obs -> 64 -> 64 ->
-// head at 76 inputs), at most STAGE2_WAVES in all, so that all wavefronts carry the same number of MFMAs.  Chunks are multiples of 16 rows.
+// head at 76 inputs), at most STAGE2_WAVES in all, so that all wavefronts carry the same number of MFMAs.  Chunks are multiples of 32 rows.
 struct Stage2Plan { int nchunks[6], mchunk[6], wave0[6], sbase[6], off[6], nwaves, total, scratch; };
 inline Stage2Plan stage2_plan(int O, int A, int m) {
   const int U[6] = {H, H, 1, H, H, A}, K1[6] = {O + 1, H + 1, H + 1, O + 1, H + 1, H + 1};
@@ -685,7 +692,7 @@ inline Stage2Plan stage2_plan(int O, int A, int m) {
   for (int i = 0; i < 6; ++i) { tiles[i] = ((U[i] + 31) / 32) * ((K1[i] - 1 + 31) / 32); all += tiles[i]; }
   for (int i = 0; i < 6; ++i) {
     const int want = STAGE2_WAVES * tiles[i] / all > 0 ? STAGE2_WAVES * tiles[i] / all : 1;       // wavefronts for this layer (rounded DOWN, chunks rounded up)
-    const int mc = (((m + want - 1) / want + 15) / 16) * 16;
+    const int mc = (((m + want - 1) / want + 31) / 32) * 32;
     P.mchunk[i] = mc; P.nchunks[i] = (m + mc - 1) / mc;
     P.wave0[i] = P.nwaves; P.sbase[i] = P.scratch; P.off[i] = P.total;
     P.nwaves += P.nchunks[i]; P.scratch += P.nchunks[i] * U[i] * K1[i]; P.total += U[i] * K1[i];
@@ -845,6 +852,7 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
                            void* stream) {
   if (int rc = check_policy(p, device_id)) return rc;
   if (!batch || !work || batch->m < 1) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: null argument or m < 1");
+  if (batch->m % 32 != 0) return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: m must be a multiple of 32 rows (the work arrays are written in tiles of 32)");
   if ((long long)batch->m * (p->obs_dim > H ? p->obs_dim : H) >= (1LL << 31))
     return solorl_fail_(SOLORL_ERR_INVALID, "solorl_ppo_grad_stage1: mini-batch too large (the [unit][row] arrays are indexed with 32 bits)");
   const void* ptrs[] = {batch->obs, batch->actions, batch->old_logp, batch->adv, batch->vpred, batch->ret, batch->perm, batch->offset,

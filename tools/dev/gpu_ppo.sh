@@ -2,7 +2,7 @@
 # PPO-side kernels: their tests, then a kernel trace of the PPO loop (rollout graph + update graphs)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-python -u -m pytest tests/test_train_gpu.py tests/test_golden_ppo.py -m gpu -q --durations=5 -x > $O/ppo_pytest_gpu.log 2>&1; rc=$?; echo "pytest rc $rc"; grep -E "passed|failed|FAILED|Error|assert" $O/ppo_pytest_gpu.log | tail -20
+python -u -m pytest tests/test_train_gpu.py tests/test_golden_ppo.py tests/test_reference_pinned_gpu.py -m gpu -q --durations=5 -x > $O/ppo_pytest_gpu.log 2>&1; rc=$?; echo "pytest rc $rc"; grep -E "passed|failed|FAILED|Error|assert" $O/ppo_pytest_gpu.log | tail -20
 [ $rc -eq 0 ] || exit $rc
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/prof_ppo -o ppo -- python3 $R/tools/dev/prof_ppo.py > $O/prof_ppo.log 2>&1; echo "rocprof rc $?"; tail -2 $O/prof_ppo.log
