@@ -74,6 +74,13 @@ def test_policy_kernel_entry_points_reject_bad_arguments(lib):
     assert lib.solorl_ppo_grad_stage2(C.byref(P), None, 64, None, 0, None) == -1
     assert lib.solorl_ppo_clip_adam(C.byref(P), None, None, 0, None) == -1
     assert lib.solorl_ppo_grad_count(76, 12) == 2 * 64 * 77 + 2 * 64 * 65 + 65 + 12 * 65
+    # stage 2's working memory (ABI 5): one block of U x (K + 1) floats per layer and chunk of rows, fewer than 1024 chunks in all (one
+    # wavefront per SIMD), chunks of whole 32-row tiles; a pure host function
+    n = lib.solorl_ppo_scratch_count(76, 12, 32768)
+    per_layer = [64 * 77, 64 * 65, 65, 64 * 77, 64 * 65, 12 * 65]
+    assert n % 1 == 0 and sum(per_layer) * 64 < n < sum(per_layer) * 1024 / 6 * 1.5
+    assert lib.solorl_ppo_scratch_count(76, 12, 0) == 0 and lib.solorl_ppo_scratch_count(76, 12, 64) == 2 * sum(per_layer)
+    assert lib.solorl_ppo_scratch_count(60, 8, 32768) < n
     if not torch.cuda.is_available():
         for k, _t in P._fields_[4:]:
             setattr(P, k, 4096)                       # non-null (never dereferenced on the host)
