@@ -313,7 +313,7 @@ int solorl_ppo_clip_adam(const solorl_policy_params* p, const solorl_ppo_grads* 
  * solorl_step do with two launches.  Why one: at 4096 envs per GPU the step launch lasts as long as its slowest wavefront while the
  * mean wavefront is done in half that time; each wavefront evaluates the policy for its own four envs as soon as their observations
  * exist, so the policy costs no launch of its own.  Needs the engine's defaults (fp32, team mode, no contact-count sorting), hidden
- * = 64, obs_dim = this env's observation size and a multiple of 4 (one history level), 16-byte aligned weight matrices; otherwise
+ * = 64, obs_dim = this env's observation size, a multiple of 4 and at most 88 (zero or one history level), 16-byte aligned weight matrices; otherwise
  * SOLORL_ERR_INVALID and the caller keeps the two-call form.  Outputs equal solorl_policy_act's on the same rows up to the order
  * of the f32 sums (tested: 2e-6). */
 int solorl_step_act(solorl_env* env, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,

@@ -513,37 +513,39 @@ SD float pol_dot4(nfloat4 w, nfloat4 x, float acc) { return fmaf(w.x, x.x, fmaf(
 #define POL_PIN4(x) asm volatile("" : "+v"(x))
 // Hidden layers, one UNIT per lane: lane L of the wavefront computes unit L of both nets for all FOUR envs of the wavefront -- a weight row
 // is loaded once per wavefront and multiplied with four observation vectors (LDS broadcast reads) instead of once per env: 70 float4
-// weight loads per lane for the two layers instead of 280.  Batches of KB input chunks x 2 nets behind a value-redefining barrier,
-// as before.
+// weight loads per lane for the two layers instead of 280.
+// One batch of weights: KB input chunks (float4) of lane L's row of both nets, issued together; and its multiply-adds against the four envs'
+// inputs.  policy_tail_team strings five batches into a software pipeline: the NEXT batch's loads are issued before the current batch's
+// arithmetic, so only the first round trip is exposed.
+template <int KB> struct PolBatch { nfloat4 c[KB], a[KB]; };
 template <int KB>
-SD void pol_layer(const float* wc_, const float* wa_, const float* bc_, const float* ba_, int K4, int lane, unsigned xoff, unsigned xoff_a, unsigned yoff) {
+SD void pol_load(PolBatch<KB>& B, const float* wc_, const float* wa_, int K4, int k0, int lane) {
   gfloat4* wc = (gfloat4*)(wc_ + (size_t)lane * 4 * K4);
   gfloat4* wa = (gfloat4*)(wa_ + (size_t)lane * 4 * K4);
-  float c[4], a[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) { c[e] = bc_[lane]; a[e] = ba_[lane]; }
-#pragma unroll 1
-  for (int k0 = 0; k0 < K4; k0 += KB) {
-    nfloat4 wcb[KB], wab[KB];
-#pragma unroll
-    for (int kk = 0; kk < KB; kk++) {
-      const int k = k0 + kk < K4 ? k0 + kk : K4 - 1;          // (past the end: the last chunk again, not accumulated)
-      wcb[kk] = wc[k]; wab[kk] = wa[k];
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int kk = 0; kk < KB; kk++) { POL_PIN4(wcb[kk]); POL_PIN4(wab[kk]); }
-#pragma unroll
-    for (int kk = 0; kk < KB; kk++)
-      if (k0 + kk < K4) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const nfloat4 xc = reinterpret_cast<const nfloat4*>(solo_smem + e * POL_ENV_BYTES + xoff)[k0 + kk];
-          const nfloat4 xa = xoff_a == xoff ? xc : reinterpret_cast<const nfloat4*>(solo_smem + e * POL_ENV_BYTES + xoff_a)[k0 + kk];
-          c[e] = pol_dot4(wcb[kk], xc, c[e]); a[e] = pol_dot4(wab[kk], xa, a[e]);
-        }
-      }
+  for (int kk = 0; kk < KB; kk++) {
+    const int k = k0 + kk < K4 ? k0 + kk : K4 - 1;          // (past the end: the last chunk again, not accumulated)
+    B.c[kk] = wc[k]; B.a[kk] = wa[k];
   }
+  asm volatile("" ::: "memory");                            // issued HERE (the scheduler would otherwise move them to their uses)
+}
+template <int KB>
+SD void pol_fma(PolBatch<KB>& B, int K4, int k0, unsigned xoff, unsigned xoff_a, float (&c)[4], float (&a)[4]) {
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int kk = 0; kk < KB; kk++) { POL_PIN4(B.c[kk]); POL_PIN4(B.a[kk]); }
+#pragma unroll
+  for (int kk = 0; kk < KB; kk++)
+    if (k0 + kk < K4) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const nfloat4 xc = reinterpret_cast<const nfloat4*>(solo_smem + e * POL_ENV_BYTES + xoff)[k0 + kk];
+        const nfloat4 xa = xoff_a == xoff ? xc : reinterpret_cast<const nfloat4*>(solo_smem + e * POL_ENV_BYTES + xoff_a)[k0 + kk];
+        c[e] = pol_dot4(B.c[kk], xc, c[e]); a[e] = pol_dot4(B.a[kk], xa, a[e]);
+      }
+    }
+}
+SD void pol_act_store(const float (&c)[4], const float (&a)[4], unsigned yoff, int lane) {
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     float* y = reinterpret_cast<float*>(solo_smem + e * POL_ENV_BYTES + yoff);
@@ -555,20 +557,40 @@ template <int A>
 SD void policy_tail_team(const PolicyTail& P, int O, int col, int t, idx_t env, bool valid) {
   float* const buf = reinterpret_cast<float*>(solo_smem + (unsigned)col * POL_ENV_BYTES);
   float* const h2 = buf + 224;              // per env: obs at 0 (<= 96 floats), h1 at 96 [critic 64 | actor 64], h2 at 224
-  const int lane = threadIdx.x & 63;
-  pol_layer<10>(P.cw0, P.aw0, P.cb0, P.ab0, O >> 2, lane, 0u, 0u, 96u * 4u);                 // layer 1: both nets read the observation
-  TEAM_SYNC();
-  pol_layer<8>(P.cw1, P.aw1, P.cb1, P.ab1, 16, lane, 96u * 4u, 160u * 4u, 224u * 4u);      // layer 2: critic reads h1[0..63], actor h1[64..127]
+  const int lane = threadIdx.x & 63, O4 = O >> 2;
   static_assert(A < 15, "the critic head sits on lane 15");
   const bool head = t < A || t == 15;
+  constexpr unsigned H1 = 96u * 4u, H2 = 224u * 4u;
+  float c[4], a[4];
+  // layer 1 (both nets read the observation) in two batches, layer 2 (critic reads h1[0..63], actor h1[64..127]) in two, then the heads' rows
+  PolBatch<11> w1a, w1b;                    // (two batches of 11 chunks: observations of up to 88 values; the widest is 84)
+  PolBatch<8> w2a, w2b;
+  nfloat4 whb[16];
+  pol_load(w1a, P.cw0, P.aw0, O4, 0, lane);
+  pol_load(w1b, P.cw0, P.aw0, O4, 11, lane);
+#pragma unroll
+  for (int e = 0; e < 4; e++) { c[e] = P.cb0[lane]; a[e] = P.ab0[lane]; }
+  pol_fma(w1a, O4, 0, 0u, 0u, c, a);
+  pol_load(w2a, P.cw1, P.aw1, 16, 0, lane);
+  pol_fma(w1b, O4, 11, 0u, 0u, c, a);
+  pol_act_store(c, a, H1, lane);
+  pol_load(w2b, P.cw1, P.aw1, 16, 8, lane);
+#pragma unroll
+  for (int e = 0; e < 4; e++) { c[e] = P.cb1[lane]; a[e] = P.ab1[lane]; }
+  TEAM_SYNC();
+  pol_fma(w2a, 16, 0, H1, H1 + 256u, c, a);
+  {
+    gfloat4* wh = (gfloat4*)(t == 15 ? P.cw2 : P.mw + (size_t)(head ? t : 0) * 64);
+#pragma unroll
+    for (int k = 0; k < 16; k++) whb[k] = wh[k];
+    asm volatile("" ::: "memory");
+  }
+  pol_fma(w2b, 16, 8, H1, H1 + 256u, c, a);
+  pol_act_store(c, a, H2, lane);
   TEAM_SYNC();
   // heads: lane t < A -> mean_t (and the action, its log-prob term), lane 15 -> value
   float out = 0.f;
   {
-    gfloat4* wh = (gfloat4*)(t == 15 ? P.cw2 : P.mw + (size_t)(head ? t : 0) * 64);
-    nfloat4 whb[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) whb[k] = wh[k];
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int k = 0; k < 16; k++) POL_PIN4(whb[k]);
@@ -1533,8 +1555,9 @@ int solorl_step_act(solorl_env* h, const float* actions, float* obs_out, float* 
   if (!h) return fail(SOLORL_ERR_INVALID, "null handle");
   if (!p || !value_out || !action_out || !logp_out) return fail(SOLORL_ERR_INVALID, "solorl_step_act: null policy argument");
   if (h->f64 || !h->team || h->sort) return fail(SOLORL_ERR_INVALID, "solorl_step_act needs the fp32 team-mode engine without contact-count sorting (the defaults)");
-  if (p->hidden != 64 || p->obs_dim != h->O || p->act_dim != h->n || (h->O & 3))
-    return fail(SOLORL_ERR_INVALID, "solorl_step_act: the policy must be the MLP of hidden size 64 on this env's observation / action sizes, obs_dim a multiple of 4");
+  if (p->hidden != 64 || p->obs_dim != h->O || p->act_dim != h->n || (h->O & 3) || h->O > 88)
+    return fail(SOLORL_ERR_INVALID, "solorl_step_act: the policy must be the MLP of hidden size 64 on this env's observation / action sizes, obs_dim a multiple of 4 "
+                                    "and at most 88 (zero or one history level)");
   const void* ptrs[] = {p->critic_w0, p->critic_b0, p->critic_w1, p->critic_b1, p->critic_w2, p->critic_b2, p->actor_w0, p->actor_b0, p->actor_w1, p->actor_b1,
                         p->mean_w, p->mean_b, p->logstd};
   for (const void* q : ptrs) if (!q) return fail(SOLORL_ERR_INVALID, "solorl_step_act: null policy parameter pointer");

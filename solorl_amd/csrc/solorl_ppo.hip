@@ -866,11 +866,11 @@ int solorl_ppo_grad_stage1(const solorl_policy_params* p, const solorl_ppo_batch
   return dispatch_dims(P.obs_dim, P.act_dim, [&](auto oc, auto ac) {
     constexpr int O = decltype(oc)::value, A = decltype(ac)::value;
     constexpr int LDS = stage1_lds_bytes<O, A>();
-    static bool lds_ok = false;              // (more than the 64 KB a kernel gets by default: raised once per instantiation)
-    if (!lds_ok) {
+    static bool lds_ok[64] = {};             // (more than the 64 KB a kernel gets by default: raised once per instantiation and device)
+    if (!lds_ok[device_id & 63]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_grad_stage1_mfma_kernel<O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
         return solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage1_mfma_kernel: cannot raise the dynamic LDS limit");
-      lds_ok = true;
+      lds_ok[device_id & 63] = true;
     }
     hipLaunchKernelGGL((ppo_grad_stage1_mfma_kernel<O, A>), dim3((B.m + 127) / 128, 2), dim3(256), LDS, (hipStream_t)stream, CRITIC_PASS, ACTOR_PASS, B, W);
     return hipGetLastError() == hipSuccess ? 0 : solorl_fail_(SOLORL_ERR_HIP, "ppo_grad_stage1_mfma_kernel launch");

@@ -186,10 +186,10 @@ class SoloVecEnv:
 
     def step_act_supported(self, params):
         """solorl_step_act (include/solorl.h): the engine's defaults (fp32, team mode, no sorting) and an observation size that is a
-        multiple of 4 floats (one history level) with the reference's hidden-64 MLP on it."""
+        multiple of 4 floats and at most 88 (zero or one history level) with the reference's hidden-64 MLP on it."""
         import os
         return (self.cfg.precision == 0 and os.environ.get("SOLORL_TEAM", "1") != "0" and os.environ.get("SOLORL_SORT", "0") == "0"
-                and self.obs_dim % 4 == 0 and params.obs_dim == self.obs_dim and params.act_dim == self.act_dim and params.hidden == 64)
+                and self.obs_dim % 4 == 0 and self.obs_dim <= 88 and params.obs_dim == self.obs_dim and params.act_dim == self.act_dim and params.hidden == 64)
 
     def step_act_inplace(self, actions, params, noise, value_out, action_out, logp_out, obs_out=None, rew_out=None, done_out=None):
         """step_inplace + Policy.act on the new observations in ONE launch (solorl_step_act): value_out [N] or [N,1], action_out [N,A] =

@@ -512,6 +512,27 @@ def test_step_act_equals_step_then_policy_act(gpu_device, robot, task, O, A, N):
     ea.close(); eb.close()
 
 
+def test_step_act_rejects_observations_wider_than_one_history_level(gpu_device):
+    """The policy tail keeps an env's observation in 96 floats of LDS and reads it in two batches of 11 float4: with the deeper history
+    levels of round 4 (num_history_stack 3: 152 values for Solo12 walk) solorl_step_act must refuse, and step_act_supported says no."""
+    from solorl_amd import _native
+    from solorl_amd.config import default_config, ROBOT_SOLO12, TASK_WALK
+    from solorl_amd.ppo.fused import policy_params
+    from solorl_amd.vec_env import SoloVecEnv
+    dev = torch.device("cuda:0")
+    cfg = default_config(ROBOT_SOLO12, TASK_WALK); cfg.num_history_stack = 3
+    env = SoloVecEnv(cfg, 8, device=dev, seed=1)
+    assert env.obs_dim == 152
+    pol = _random_policy(dev, 152, 12, seed=3)
+    P = policy_params(pol)
+    assert not env.step_act_supported(P)
+    env.reset()
+    v, a, l = torch.empty(8, 1, device=dev), torch.empty(8, 12, device=dev), torch.empty(8, 1, device=dev)
+    with pytest.raises(_native.SoloRLError, match="at most 88"):
+        env.step_act_inplace(torch.zeros(8, 12, device=dev), P, None, v, a, l)
+    env.close()
+
+
 def test_graphed_rollout_with_step_act_replays_like_the_two_launch_form(gpu_device, monkeypatch):
     """GraphedRollout on solorl_step_act (one launch per step, the default where supported) against the two-launch form
     (SOLORL_STEP_ACT=0) from the same seeds: the first observation row and its value agree, and each storage is internally consistent --
