@@ -115,7 +115,7 @@ def policy_act(params, obs, noise, value_out, action_out, logp_out):
 
 class MiniBatchGrad:
     """One PPO mini-batch step's gradients without autograd, three launches: solorl_ppo_grad_stage1 (gather, forward, losses,
-    back-propagation to every layer's pre-activation gradient, [unit][row] layout), then solorl_ppo_grad_stage2 (the weight
+    back-propagation to every layer's pre-activation gradient, written in tiles [row / 32][unit][32]), then solorl_ppo_grad_stage2 (the weight
     gradients G^T X of the six layers over row chunks, and their fixed-order sum written straight into the parameters' .grad --
     views of the flat bucket -- with the log-std gradient and the running loss sums).  Same arithmetic as PPO.update's
     loss.backward() (agents/ppo/ppo.py:46-74) in a different summation order."""
