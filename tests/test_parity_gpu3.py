@@ -51,7 +51,7 @@ def _rollout_stats(step, reset, act, T):
 
 @pytest.mark.parametrize("stochastic", [False, True])
 @pytest.mark.parametrize("name,cfg_file,task", [("stand8", "basic.yaml", "stand"), ("pointgoal12", "basic12.yaml", "pointgoal"),
-                                                 ("walk8", "basic.yaml", "walk")])
+                                                 ("walk8", "basic.yaml", "walk"), ("walk12", "basic12.yaml", "walk")])
 def test_trained_policy_statistics_engine_vs_oracle(gpu_device, name, cfg_file, task, stochastic):
     """VERDICT r03 "Next" #2.  The same deterministic policy (action = mean, agents/ppo/policy.py:33-45 `deterministic=True`) -- and the
     same policy as it was trained, action = mean + exp(logstd) * noise with ONE host-side noise sequence shared by all simulators (the
