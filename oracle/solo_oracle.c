@@ -135,6 +135,8 @@ struct oracle_env {
   int opt_gyro;                  /* 1 (default): gyroscopic term w x I w (btMultiBody::m_useGyroTerm) */
   int opt_limit_split;           /* 1: a joint more than 0.04 rad beyond its limit loses the positional term (btMultiBodyJointLimitConstraint with
                                   * m_splitImpulse on and no split-impulse pass for multibodies) and uses erp2 */
+  int opt_foot_points;           /* primitives: 1 (default) one support point per foot; 2: BOTH edges of the 4 mm tread (y = +-ring_y[0]) as separate points --
+                                  * the cheapest stand-in for the multi-point patch Bullet's manifold keeps under a foot (K6 experiment) */
   int opt_manifold_persist;      /* manifold model: 1 (default) Bullet's persistent <= 4-point cache; 0: only this step's support vertex (ablation: geometry vs caching) */
   double opt_break_scale;        /* scale of every contact-breaking threshold (gContactBreakingThreshold 0.02) */
   int64_t (*iter_hist)[ITER_HIST]; /* [N][ITER_HIST]: sub-steps that had rows, by the number of PGS sweeps they ran */
@@ -322,6 +324,41 @@ static int collide_primitives(const oracle_env* E, const solorl_env_state* s, co
     double P[3];
     if ((skip_links >> prim_of(E, p)->link) & 1u) continue;
     /* a collision margin m around a shape (its Minkowski sum with a sphere) lowers the support point towards the plane by m */
+    const solorl_prim_data* pr = prim_of(E, p);
+    if (E->opt_foot_points >= 2 && pr->nring > 1 && pr->axis >= 0) {
+      /* K6 experiment: the two edges of the tread, each its own contact point (sharp edges: no smooth crossing of the tread) */
+      const int l = pr->link;
+      double up[3] = {0, 0, 1}, dd[3];
+      m3tmulv(dd, K->R[l], up);
+      for (int k = 0; k < 3; k++) dd[k] = -dd[k];
+      dd[pr->axis] = 0;
+      const double inv = pr->ring_r[0] / sqrt(v3dot(dd, dd) + DISC_EPS2);
+      for (int side = -1; side <= 1; side += 2) {
+        double loc[3]; v3cpy(loc, pr->center);
+        v3axpy(loc, inv, dd);
+        loc[pr->axis] += side * pr->ring_y[0];
+        if (E->opt_foot_points == 3) {
+          /* ONE point: the support VERTEX of a 53-gon tread with two sharp edges (what the foot hull's own tread is: 53 vertices 6.79 degrees
+           * apart on each edge ring, one of them at 180 degrees) -- the contact point jumps by 1.9 mm along the tread and by 4 mm across it */
+          const int a0 = (pr->axis + 1) % 3, a1 = (pr->axis + 2) % 3;
+          const double da = -K->R[l][6 + pr->axis];            /* world down along the wheel axis */
+          if ((da >= 0 ? 1 : -1) != side) continue;
+          const double step = 2.0 * M_PI / 53.0, th = atan2(dd[a1], dd[a0]);
+          const double thq = M_PI + step * floor((th - M_PI) / step + 0.5);
+          v3cpy(loc, pr->center);
+          loc[a0] += pr->ring_r[0] * cos(thq); loc[a1] += pr->ring_r[0] * sin(thq);
+          loc[pr->axis] += side * pr->ring_y[0];
+        }
+        m3mulv(P, K->R[l], loc); v3add(P, P, K->o[l]);
+        const double d2 = P[2] - E->cfg.collision_margin;
+        P[2] = d2;
+        if (d2 < pr->margin * E->opt_break_scale) {
+          cpoint_t* c = &cp[n++];
+          c->link = l; c->id = p; c->prim = 1; v3cpy(c->P, P); c->dist = d2; c->friction = pr->friction; c->lam0 = 0;
+        }
+      }
+      continue;
+    }
     const double d = prim_point(E, K, p, P) - E->cfg.collision_margin;
     P[2] = d;
     if (d < prim_of(E, p)->margin * E->opt_break_scale) {
@@ -801,7 +838,7 @@ oracle_env* oracle_create(const solorl_config* cfg, int num_envs, uint64_t seed,
   E->last_counts = calloc((size_t)num_envs * 4, sizeof *E->last_counts);
   E->man = calloc((size_t)num_envs * NL_MAX, sizeof *E->man);
   E->iter_hist = calloc((size_t)num_envs, sizeof *E->iter_hist);
-  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_break_scale = 1; E->opt_manifold_persist = 1;
+  E->opt_friction_skip = 0; E->opt_gyro = 1; E->opt_limit_split = 0; E->opt_break_scale = 1; E->opt_manifold_persist = 1; E->opt_foot_points = 1;
   E->hulls = cfg->robot == SOLORL_ROBOT_SOLO12 ? ORACLE_HULLS_SOLO12 : ORACLE_HULLS_SOLO8;
   E->contact_model = 0; E->cap_contacts = 0; E->cap_limits = 0; E->manifold_links = ~0u;
   if (getenv("ORACLE_MANIFOLD_LINKS")) E->manifold_links = (unsigned)strtoul(getenv("ORACLE_MANIFOLD_LINKS"), NULL, 0);
@@ -822,6 +859,7 @@ int oracle_set_option(oracle_env* E, const char* name, double v) {
   else if (!strcmp(name, "limit_split")) E->opt_limit_split = v != 0;
   else if (!strcmp(name, "breaking_scale")) E->opt_break_scale = v;
   else if (!strcmp(name, "manifold_persist")) E->opt_manifold_persist = v != 0;
+  else if (!strcmp(name, "foot_points")) E->opt_foot_points = v >= 3 ? 3 : (v >= 2 ? 2 : 1);   /* 3: the support vertex of the polygonal tread (one point) */
   else return -1;
   return 0;
 }
