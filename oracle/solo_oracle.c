@@ -325,6 +325,24 @@ static int collide_primitives(const oracle_env* E, const solorl_env_state* s, co
     if ((skip_links >> prim_of(E, p)->link) & 1u) continue;
     /* a collision margin m around a shape (its Minkowski sum with a sphere) lowers the support point towards the plane by m */
     const solorl_prim_data* pr = prim_of(E, p);
+    if (E->opt_foot_points == 4 && pr->nring > 1 && pr->axis >= 0) {
+      /* K6 cross-check: ONE point through the primitive path, but the support vertex of the link's ACTUAL hull (the vertex set the manifold
+       * model searches) -- separates the hull's geometry from everything else collide_manifolds does */
+      const int l = pr->link;
+      const oracle_hull* H = &E->hulls[l];
+      const double* R = K->R[l];
+      int best = 0; double zb = 1e30;
+      for (int i = 0; i < H->n; i++) { const double z = R[6] * H->v[i][0] + R[7] * H->v[i][1] + R[8] * H->v[i][2]; if (z < zb) { zb = z; best = i; } }
+      double loc[3] = {H->v[best][0], H->v[best][1], H->v[best][2]};
+      m3mulv(P, R, loc); v3add(P, P, K->o[l]);
+      const double d4 = P[2] - E->cfg.collision_margin;
+      P[2] = d4;
+      if (d4 < pr->margin * E->opt_break_scale) {
+        cpoint_t* c = &cp[n++];
+        c->link = l; c->id = p; c->prim = 1; v3cpy(c->P, P); c->dist = d4; c->friction = pr->friction; c->lam0 = 0;
+      }
+      continue;
+    }
     if (E->opt_foot_points >= 2 && pr->nring > 1 && pr->axis >= 0) {
       /* K6 experiment: the two edges of the tread, each its own contact point (sharp edges: no smooth crossing of the tread) */
       const int l = pr->link;
@@ -859,7 +877,7 @@ int oracle_set_option(oracle_env* E, const char* name, double v) {
   else if (!strcmp(name, "limit_split")) E->opt_limit_split = v != 0;
   else if (!strcmp(name, "breaking_scale")) E->opt_break_scale = v;
   else if (!strcmp(name, "manifold_persist")) E->opt_manifold_persist = v != 0;
-  else if (!strcmp(name, "foot_points")) E->opt_foot_points = v >= 3 ? 3 : (v >= 2 ? 2 : 1);   /* 3: the support vertex of the polygonal tread (one point) */
+  else if (!strcmp(name, "foot_points")) E->opt_foot_points = v >= 4 ? 4 : (v >= 3 ? 3 : (v >= 2 ? 2 : 1));   /* 4: the support vertex of the link's actual hull, through the primitive path */   /* 3: the support vertex of the polygonal tread (one point) */
   else return -1;
   return 0;
 }

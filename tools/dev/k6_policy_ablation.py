@@ -61,6 +61,7 @@ run("  friction pyramid", over={"friction_model": 0})
 run("  contact erp 0.2", over={"contact_erp": 0.2})
 run("  both tread edges per foot (foot_points 2)", opts={"foot_points": 2})
 run("  support vertex of a 53-gon tread (foot_points 3)", opts={"foot_points": 3})
+run("  support vertex of the foot HULL, primitive path (foot_points 4)", opts={"foot_points": 4})
 run("hull manifolds: all links", mask=ALL)
 run("  feet only", mask=FEET)
 run("  feet only, no persistent cache", mask=FEET, persist=0)
