@@ -3,7 +3,7 @@ tests/golden/policies/ (mean action / with its exploration noise; 256 envs x 450
   * solver / friction variants on the policy's own contact model (is the gait brittle?),
   * Bullet-style hull manifolds for ONE link class, primitives elsewhere (which links carry the gap?),
   * two cheap stand-ins for the foot hull on the primitives (oracle option foot_points).
-usage: k6_policy_ablation.py [walk12|walk8|stand8|pointgoal12]      (DESIGN.md section 3 K6 iii-iv, profiles/r04_notes.md)"""
+usage: k6_policy_ablation.py [walk12|walk8|stand8|pointgoal12] [checkpoint.pt]      (DESIGN.md section 3 K6 iii-iv, profiles/r04_notes.md)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -18,7 +18,9 @@ CFG = {"walk12": ("basic12.yaml", "walk"), "walk8": ("basic.yaml", "walk"), "sta
 d = load_yaml(os.path.join(ROOT, "configs", CFG[0])); d["task"] = CFG[1]
 c = config_from_dict(d)
 pol = Policy((c.obs_dim,), Box(-np.ones(c.n_joints), np.ones(c.n_joints)), None, {"hidden_size": 64})
-pol.load_state_dict(torch.load(os.path.join(ROOT, "tests", "golden", "policies", NAME + ".pt"), map_location="cpu", weights_only=True)); pol.eval()
+CKPT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golden", "policies", NAME + ".pt")      # optional: another checkpoint of the same shape
+_sd = torch.load(CKPT, map_location="cpu", weights_only=False)
+pol.load_state_dict(_sd["state_dict"] if "state_dict" in _sd else _sd); pol.eval()
 std = pol.pi_dist.logstd.detach().exp().numpy().reshape(1, -1)
 N, T = 256, 450
 noise = np.random.default_rng(77).standard_normal((T, N, c.n_joints)).astype(np.float32)
@@ -53,7 +55,7 @@ def run(label, mask=None, persist=1, over=None, opts=None):
 
 ALL = (1 << NL) - 1
 FEET = cls(per - 1)
-print("== %s (%s --task %s): success with the mean action / with noise" % (NAME, CFG[0], CFG[1]))
+print("== %s (%s --task %s%s): success with the mean action / with noise" % (NAME, CFG[0], CFG[1], ", " + os.path.relpath(CKPT, ROOT) if len(sys.argv) > 2 else ""))
 run("primitives (the model it was trained on)")
 run("  400 sweeps, no residual exit", over={"solver_iterations": 400, "solver_residual_threshold": 0.0})
 run("  200 sweeps", over={"solver_iterations": 200})

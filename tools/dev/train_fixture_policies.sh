@@ -1,7 +1,7 @@
 #!/bin/bash
 # Trains the small policies committed under tests/golden/policies/ (VERDICT r03 "Next" #2: trained-policy parity test): README recipe
 # (lr 2.5e-4, entropy 0.01, clip 0.1, 5 epochs, GAE, linear lr decay), 4096 envs, one GPU.  python writes straight into a log under
-# gpurun_out/ (no pipe).  usage: train_fixture_policies.sh [which...]   which = stand8 pointgoal12 walk8 walk12 walk12long
+# gpurun_out/ (no pipe).  usage: train_fixture_policies.sh [which...]   which = stand8 pointgoal12 walk8 walk12 walk12long walk8long
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/policies; mkdir -p $O; cd $R
 COMMON="--num-agents 4096 --use-gae --use-linear-lr-decay --lr 2.5e-4 --entropy-coef 0.01 --clip-param 0.1 --ppo-epoch 5 --mini-batch-size 32768 --seed 1 --log-interval 100 --save-interval 100000"
 run() {   # name config task steps limit
@@ -16,5 +16,6 @@ for w in ${@:-stand8 pointgoal12 walk8}; do
     walk8) run walk8 basic.yaml walk 8e9 900 || exit 1;;
     walk12) run walk12 basic12.yaml walk 8e9 900 || exit 1;;
     walk12long) run walk12long basic12.yaml walk 1.6e10 1150 || exit 1;;
+    walk8long) run walk8long basic.yaml walk 1.6e10 1150 || exit 1;;
   esac
 done
