@@ -10,6 +10,7 @@
   * `num_history_stack` 3 and 4.
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -97,14 +98,20 @@ def test_trained_policy_statistics_engine_vs_oracle(gpu_device, name, cfg_file, 
             clock[0] += 1
             return a.contiguous()
 
+        t0 = time.time()
         res[label] = _rollout_stats(step, lambda env=env: env.reset().cpu().numpy().astype(np.float64), act, T)
+        res[label]["seconds"] = time.time() - t0
         env.close()
     try:
-        threads = min(16, len(os.sched_getaffinity(0)))
+        threads = min(8, len(os.sched_getaffinity(0)))
     except AttributeError:
         threads = 4
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(1)              # the CPU policy is a 76 x 64 x 64 MLP on 256 rows: torch's default (one thread per host core, 64 on the GPU box
+                                          # against a 16-core quota) spends its time in its own thread pool -- 13 of a rollout's 15 s
     for label, model in (("oracle", 0), ("oracle_hull_manifolds", 1)):
-        orc = Oracle(c, N, seed=5, threads=threads)
+        Nm = N
+        orc = Oracle(c, Nm, seed=5, threads=threads)
         if model:
             orc.set_contact_model(1)
 
@@ -118,14 +125,17 @@ def test_trained_policy_statistics_engine_vs_oracle(gpu_device, name, cfg_file, 
             with torch.no_grad():
                 a = pol_cpu.act(torch.from_numpy(obs.astype(np.float32)), deterministic=True)[1].numpy()
             if stochastic:
-                a = a + std * noise[oclock[0]]
+                a = a + std * noise[oclock[0]][:a.shape[0]]
             oclock[0] += 1
             return a.astype(np.float64)
 
+        t0 = time.time()
         res[label] = _rollout_stats(ostep, orc.reset, oact, T)
+        res[label]["seconds"] = time.time() - t0
+    torch.set_num_threads(torch_threads)
     for k, v in res.items():
-        print("trained[%s%s] %-22s episodes %4d success %.3f length %6.1f z %.4f reward p10/p50/p90 %.3f / %.3f / %.3f" % (
-            name, " + noise" if stochastic else "", k, v["episodes"], v["success"], v["length"], v["z"], v["r10"], v["r50"], v["r90"]))
+        print("trained[%s%s] %-22s episodes %4d success %.3f length %6.1f z %.4f reward p10/p50/p90 %.3f / %.3f / %.3f  (%.1f s)" % (
+            name, " + noise" if stochastic else "", k, v["episodes"], v["success"], v["length"], v["z"], v["r10"], v["r50"], v["r90"], v["seconds"]))
     out = os.path.join(ROOT, "gpurun_out")
     try:
         import json
