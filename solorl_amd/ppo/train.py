@@ -64,6 +64,8 @@ def rollout(envs, actor_critic, storage, num_steps):
 def train(args, config, env_constructor=None, writer=None):
     from ..vec_env import make_vec_envs
     rank, world = D.init_from_env("cuda" if args.cuda else "cpu")
+    torch.set_num_threads(1)                          # as the reference's learner (train.py:29); with one process per GPU the host work is a few scalars,
+                                                      # and torch's default pool (one thread per host core) only competes with the other ranks
     torch.manual_seed(args.seed)                      # identical initial weights on every rank (train.py:23)
     if args.cuda:
         torch.cuda.manual_seed_all(args.seed)
